@@ -1,0 +1,302 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Thin extern "C" harness around the *real* reference implementation.  It does not
+// contain any reference code: the reference sources are #included BY PATH at build time
+// from the read-only mount /root/reference (same unity-build order as
+// /root/reference/main.cpp:1-9) and the resulting shared object is written to
+// oracle/_ref/ (git-ignored).  Nothing under /root/reference is copied into this repo.
+//
+// What it adds on top of the reference:
+//   * template instantiations for key widths the shipped binary does not dispatch
+//     (src/Assemble.cpp:31-53 only has k in {5,21,25,63,101,...}); the templates
+//     themselves are generic;
+//   * flat-buffer marshalling (bases + offsets -> ReadSet with names "r<i>");
+//   * read access to the private BF<Key>::m_bits (src/bloomfilter.cpp:27-28) via the
+//     `private -> public` macro, placed AFTER the STL headers are included.
+//
+// Build: see oracle/Makefile (target _ref/libp3ref.so).  Only usable where
+// /root/reference exists (the build container); the GPU box uses the prebuilt .so.
+
+#include "/root/reference/src/common.h"   // pulls in every STL header the reference uses
+#define private public                    // after the STL includes
+#include "/root/reference/src/ShowInfo.cpp"
+#include "/root/reference/src/Options.cpp"
+#include "/root/reference/src/Load.cpp"
+#include "/root/reference/src/bloomfilter.cpp"
+#include "/root/reference/src/MakeBloomFilter.cpp"
+#include "/root/reference/src/DeBruijnGraph.cpp"
+#include "/root/reference/src/Assemble.cpp"
+#include "/root/reference/src/Logging.cpp"
+#undef private
+
+#include <chrono>
+#include <cstring>
+#include <cstdio>
+
+namespace {
+
+// every supported large-k (1- and 2-word keys).  X(k)
+#define P3REF_KLIST(X) \
+  X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) \
+  X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) \
+  X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Session {
+  Options options;
+  Logging logging;
+  ReadFile* reads = nullptr;
+  std::set<std::string> seeds;
+  double t_count = 0, t_bloom = 0;
+};
+
+void fill_reads(Session& s, const char* bases, const uint64_t* offsets, uint64_t n_reads, int k) {
+  s.options.readfile_name = "x.fasta";      // ReadFile ctor takes substr(size-5,5) (src/Load.cpp:26)
+  s.options.kmer_length = k;
+  s.logging.log_file = "/dev/null";
+  s.reads = new ReadFile(s.options);
+  for (uint64_t i = 0; i < n_reads; i++) {
+    std::string seq(bases + offsets[i], bases + offsets[i + 1]);
+    // same admission rule as src/Load.cpp:59-61 (reads shorter than k are dropped)
+    if (seq.size() >= (size_t)k) {
+      s.reads->reads[">r" + std::to_string(i)] = seq;
+      s.reads->all_bases += seq.size();
+    }
+  }
+}
+
+template <typename B>
+void words_of(const B& b, uint64_t* out, int nwords) {
+  // libstdc++ bitset: bit i lives in word i/64 (LSB-first).  Extract portably bit by bit.
+  for (int w = 0; w < nwords; w++) out[w] = 0;
+  for (size_t i = 0; i < b.size(); i++)
+    if (b[i]) out[i / 64] |= (1ULL << (i % 64));
+}
+
+template <typename B>
+B bitset_of(const uint64_t* w) {
+  B b(0);
+  for (size_t i = 0; i < b.size(); i++)
+    if ((w[i / 64] >> (i % 64)) & 1) b.set(i);
+  return b;
+}
+
+template <typename B>
+int make_bf_t(Session& s, int k, uint64_t m, int H, uint64_t* bloom_words, char* seed_chars,
+              uint64_t seed_cap, uint64_t* n_seeds) {
+  s.seeds.clear();
+  double t0 = now_s();
+  BF<B> bf = MakeBF<B>(s.reads->reads, s.reads->shortk_database, m, (uint8_t)H, k, &s.seeds, s.logging);
+  s.t_bloom = now_s() - t0;
+  uint64_t nw = (m + 63) / 64;
+  for (uint64_t w = 0; w < nw; w++) bloom_words[w] = 0;
+  for (uint64_t i = 0; i < m; i++)
+    if (bf.m_bits[i]) bloom_words[i >> 6] |= (1ULL << (i & 63));
+  *n_seeds = s.seeds.size();
+  if (s.seeds.size() > seed_cap) return 3;
+  uint64_t j = 0;
+  for (const auto& sd : s.seeds) {   // std::set order = sorted by string
+    std::memcpy(seed_chars + j * k, sd.data(), k);
+    j++;
+  }
+  return 0;
+}
+
+template <typename B>
+int assemble_t(Session& s, int k, uint64_t m, int H, int threads, const char* workdir) {
+  // Same call order as src/Assemble.cpp:6-28, but with explicit (m,H) and a scratch cwd
+  // because PrintGraph writes ./de_bruijn_graph.gfa (src/DeBruijnGraph.cpp:454).
+  char old[4096];
+  if (!getcwd(old, sizeof old)) return 4;
+  if (chdir(workdir) != 0) return 4;
+  s.reads->CountShortKmer(s.options.shortk_length);
+  std::set<std::string> seedkmer;
+  BF<B> bf = MakeBF<B>(s.reads->reads, s.reads->shortk_database, m, (uint8_t)H, k, &seedkmer, s.logging);
+  DeBruijnGraph<B> dbg(k, bf, s.logging);
+  dbg.MakeDBG(seedkmer, m, (uint8_t)H, threads);
+  dbg.CountNodeCoverage(s.reads->reads);
+  dbg.PrintGraph();
+  if (chdir(old) != 0) return 4;
+  return 0;
+}
+
+template <typename B>
+void kat_t(const char* seq, int k, uint64_t m, int H, uint64_t* fwd, uint64_t* rc, uint64_t* comp_of_fwd,
+           uint64_t* canon, uint64_t* stdhash, uint64_t* h12, uint64_t* pos) {
+  int nw = (2 * k + 63) / 64;
+  std::string sseq(seq);
+  B f = GetFirstKmerForward<B>(sseq);
+  B r = GetFirstKmerBackward<B>(sseq);
+  B c = GetComplementKmer<B>(f);
+  B cn = CompareBit<B>(f, r, 2 * k);
+  words_of(f, fwd, nw);
+  words_of(r, rc, nw);
+  words_of(c, comp_of_fwd, nw);
+  words_of(cn, canon, nw);
+  *stdhash = std::hash<B>()(cn);
+  GetDoubleHash_64bit<B>(&cn, h12);
+  BF<B> bf(m, (uint8_t)H);
+  for (int n = 0; n < H; n++) pos[n] = bf.nthHash((uint8_t)n, h12[0], h12[1], m);
+}
+
+template <typename B>
+void hash_words_t(const uint64_t* words, uint64_t n, int k, uint64_t* stdhash, uint64_t* h1, uint64_t* h2) {
+  int nw = (2 * k + 63) / 64;
+  for (uint64_t i = 0; i < n; i++) {
+    B b = bitset_of<B>(words + i * nw);
+    stdhash[i] = std::hash<B>()(b);
+    uint64_t o[2];
+    GetDoubleHash_64bit<B>(&b, o);
+    h1[i] = o[0];
+    h2[i] = o[1];
+  }
+}
+
+template <typename B>
+void bloom_query_t(const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* keys, uint64_t n, int k,
+                   uint8_t* out) {
+  BF<B> bf(m, (uint8_t)H);
+  for (uint64_t i = 0; i < m; i++)
+    if ((bloom_words[i >> 6] >> (i & 63)) & 1) bf.m_bits[i] = true;
+  int nw = (2 * k + 63) / 64;
+  for (uint64_t i = 0; i < n; i++) {
+    B b = bitset_of<B>(keys + i * nw);
+    out[i] = bf.possiblyContains(&b, 2 * k) ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void* p3ref_open(const char* bases, const uint64_t* offsets, uint64_t n_reads, int k) {
+  Session* s = new Session();
+  fill_reads(*s, bases, offsets, n_reads, k);
+  return s;
+}
+
+void p3ref_close(void* h) {
+  Session* s = (Session*)h;
+  delete s->reads;
+  delete s;
+}
+
+uint64_t p3ref_all_bases(void* h) { return ((Session*)h)->reads->all_bases; }
+uint64_t p3ref_n_reads(void* h) { return ((Session*)h)->reads->reads.size(); }
+
+// Options::EstimateBloomfilter (src/Options.cpp:50-60) on the real code.
+void p3ref_estimate_bloom(uint64_t all_bases, int k, uint64_t m_in, uint64_t* m_out, int* H_out) {
+  Options o;
+  Logging lg;
+  lg.log_file = "/dev/null";
+  o.kmer_length = k;
+  o.filter_size = m_in;
+  o.EstimateBloomfilter(all_bases, lg);
+  *m_out = o.filter_size;
+  *H_out = o.num_hashes;
+}
+
+// ReadFile::CountShortKmer(21) (src/Load.cpp:105-127) -> (key,count) sorted by key.
+int p3ref_count_short(void* h, uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n_out) {
+  Session* s = (Session*)h;
+  double t0 = now_s();
+  s->reads->CountShortKmer(s->options.shortk_length);
+  s->t_count = now_s() - t0;
+  const KmerCount& kc = s->reads->shortk_database;
+  *n_out = kc.size();
+  if (kc.size() > cap) return 3;
+  std::vector<std::pair<uint64_t, uint64_t>> v;
+  v.reserve(kc.size());
+  for (const auto& kv : kc) v.push_back({kv.first.to_ullong(), kv.second});
+  std::sort(v.begin(), v.end());
+  for (size_t i = 0; i < v.size(); i++) {
+    keys[i] = v[i].first;
+    counts[i] = v[i].second;
+  }
+  return 0;
+}
+
+// MakeBF<bitset<2k>> (src/MakeBloomFilter.cpp:24-89).  Requires p3ref_count_short first.
+int p3ref_make_bf(void* h, int k, uint64_t m, int H, uint64_t* bloom_words, char* seed_chars,
+                  uint64_t seed_cap, uint64_t* n_seeds) {
+  Session* s = (Session*)h;
+  switch (k) {
+#define X(K) case K: return make_bf_t<std::bitset<2 * K>>(*s, k, m, H, bloom_words, seed_chars, seed_cap, n_seeds);
+    P3REF_KLIST(X)
+#undef X
+    default: return 2;
+  }
+}
+
+void p3ref_last_times(void* h, double* t_count, double* t_bloom) {
+  Session* s = (Session*)h;
+  *t_count = s->t_count;
+  *t_bloom = s->t_bloom;
+}
+
+// Whole Assemble<B> sequence (src/Assemble.cpp:6-28); GFA lands in <workdir>/de_bruijn_graph.gfa.
+int p3ref_assemble(void* h, int k, uint64_t m, int H, int threads, const char* workdir) {
+  Session* s = (Session*)h;
+  switch (k) {
+#define X(K) case K: return assemble_t<std::bitset<2 * K>>(*s, k, m, H, threads, workdir);
+    P3REF_KLIST(X)
+#undef X
+    default: return 2;
+  }
+}
+
+// Known-answer primitives on one k-mer string (E1,E2,E4,E5,H1,H2,B1).
+int p3ref_kat(const char* seq, int k, uint64_t m, int H, uint64_t* fwd, uint64_t* rc, uint64_t* comp_of_fwd,
+              uint64_t* canon, uint64_t* stdhash, uint64_t* h12, uint64_t* pos) {
+  if ((int)std::strlen(seq) != k) return 1;
+  switch (k) {
+#define X(K) case K: kat_t<std::bitset<2 * K>>(seq, k, m, H, fwd, rc, comp_of_fwd, canon, stdhash, h12, pos); return 0;
+    P3REF_KLIST(X)
+#undef X
+    default: return 2;
+  }
+}
+
+// std::hash<bitset<2k>> + GetDoubleHash_64bit on raw key words (H1,H2).
+int p3ref_hash_words(const uint64_t* words, uint64_t n, int k, uint64_t* stdhash, uint64_t* h1, uint64_t* h2) {
+  switch (k) {
+#define X(K) case K: hash_words_t<std::bitset<2 * K>>(words, n, k, stdhash, h1, h2); return 0;
+    P3REF_KLIST(X)
+#undef X
+    default: return 2;
+  }
+}
+
+// BF::possiblyContains (src/bloomfilter.cpp:76-86) on a given bit vector (B2).
+int p3ref_bloom_query(const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* keys, uint64_t n, int k,
+                      uint8_t* out) {
+  switch (k) {
+#define X(K) case K: bloom_query_t<std::bitset<2 * K>>(bloom_words, m, H, keys, n, k, out); return 0;
+    P3REF_KLIST(X)
+#undef X
+    default: return 2;
+  }
+}
+
+// E1/E2/E6 with arbitrary characters (unknown-character rule), 42-bit keys.
+void p3ref_encode21(const char* s, uint64_t* fwd, uint64_t* rc, char* dec_fwd, char* dec_rc) {
+  std::bitset<42> f = GetFirstKmerForward<std::bitset<42>>(std::string(s));
+  std::bitset<42> r = GetFirstKmerBackward<std::bitset<42>>(std::string(s));
+  *fwd = f.to_ullong();
+  *rc = r.to_ullong();
+  std::string a = GetStringKmer(f), b = GetStringKmer(r);
+  std::memcpy(dec_fwd, a.data(), 21);
+  std::memcpy(dec_rc, b.data(), 21);
+}
+
+// RMQ (src/MakeBloomFilter.cpp:8-22)
+uint64_t p3ref_rmq(const uint64_t* v, uint64_t n, int x, uint64_t* out) {
+  std::vector<uint64_t> r = RMQ(std::vector<uint64_t>(v, v + n), x);
+  for (size_t i = 0; i < r.size(); i++) out[i] = r[i];
+  return r.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+"""In-tree builds: the HIP/C-ABI library (hipcc, gfx950) and the CPU-only synthetic-read generator (gcc).
+
+Everything lands next to the sources in platanus3_amd/csrc/ (git-ignored, but shipped to the GPU box).
+"""
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libplatanus3_amd.so")
+SYNTH = os.path.join(CSRC, "libp3synth.so")
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hip_sources():
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".c"))]
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hpp", ".cuh"))]
+    deps += [os.path.join(INCLUDE, f) for f in sorted(os.listdir(INCLUDE))]
+    return srcs, deps
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "p3_synth.c")
+    if force or _newer(SYNTH, [src]):
+        subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-o", SYNTH, src])
+    return SYNTH
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_lib(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> libplatanus3_amd.so (cross-compiles without a GPU)."""
+    srcs, deps = _hip_sources()
+    if not (force or _newer(LIB, srcs + deps)):
+        return LIB
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
+           "-I" + INCLUDE, "-I" + CSRC, "-o", LIB + ".tmp"] + [s for s in srcs if s.endswith(".hip")]
+    # the plain-C generator is compiled separately (hipcc would treat .c as HIP-less C anyway)
+    obj = os.path.join(CSRC, "p3_synth.o")
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-c", "-o", obj, os.path.join(CSRC, "p3_synth.c")])
+    cmd.append(obj)
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def build_all(force=False):
+    build_synth(force)
+    build_lib(force)
