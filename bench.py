@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s through the count -> gate -> Bloom -> seed pass at k=31 (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W                                  (single MI355X)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (one rank per GPU)
+
+A "step" is one whole pass (reference CountShortKmer + MakeBF, src/Assemble.cpp:9-12) over one batch
+of synthetic reads that is already resident in HBM as 1 B/base ASCII + offsets.  Workload at N=1 =
+BASELINE config #2 (1 M x 150 bp, k=31, Bloom sizing from Options::EstimateBloomfilter).  For N>1 the
+per-GPU batch is fixed (weak scaling): N x 1 M reads drawn from one common genome, sharded by read index.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the roofline and cpu_baseline objects).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads PER GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def bloom_sizing(all_bases, k):
+    """Options::EstimateBloomfilter (src/Options.cpp:50-60) -- plain host arithmetic of the reference's
+    config layer, restated here so that the bench's product leg does not need the oracle."""
+    import math
+    item_number = int(all_bases * 0.0005 * k)
+    m = int((item_number * (-(math.log(1.0e-6)))) / (math.log(2) ** 2))
+    H = int((math.log(2) * m) / item_number) & 0xff
+    return m, H
+
+
+def cpu_baseline(args, k):
+    """The reference CPU path (or its reference-shaped port) on a bounded sample, 1 core."""
+    import platanus3_amd.synth as synth
+    from oracle.p3_oracle import Oracle, RefLib
+    n = args.cpu_sample_reads
+    b, o = synth.reads(seed=args.seed, total_reads=n, read_len=args.read_len)
+    m, H = bloom_sizing(int(b.size), k)
+    n_k = n * (args.read_len - k + 1)
+    if os.path.exists(RefLib.PATH):
+        ref = RefLib()
+        out = ref.run((b, o), k, m, H)
+        t = out["t_count"] + out["t_bloom"]
+        kind = "reference"
+    else:
+        out = Oracle().refshaped_pass((b, o), k, m, H)
+        t = out["t_count"] + out["t_bloom"]
+        kind = "port"
+    return {"value": n_k / t, "unit": "k-mers/s", "cores": 1, "kind": kind,
+            "host_cores": os.cpu_count(),
+            "sample": "%d x %d bp synthetic reads (same generator, 30x coverage), k=%d, m=%d, H=%d; "
+                      "CountShortKmer %.2f s + MakeBF %.2f s single-threaded" % (n, args.read_len, k, m, H,
+                                                                              out["t_count"], out["t_bloom"])}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    import platanus3_amd.synth as synth
+    from platanus3_amd import capi
+    from platanus3_amd.pipeline import Pipeline
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    k, L = args.k, args.read_len
+    total_reads = args.reads * world
+    b, o = synth.reads(seed=args.seed, total_reads=total_reads, first_read=rank * args.reads, n_reads=args.reads,
+                       read_len=L)
+    all_bases = total_reads * L
+    m, H = bloom_sizing(all_bases, k)
+    n_k_total = total_reads * (L - k + 1)
+
+    pipe = Pipeline(device=local_rank, rank=rank, world=world)
+    pipe.load_reads(b, o, min_len=k)  # H2D, untimed: inputs are resident in HBM when the clock starts
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pipe.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.run_pass(k, m, H)
+    pipe.ctx.reset_kernel_stats()
+    pipe.ctx.set_profiling(True)  # HIP events around every kernel launch, on the library's own stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run_pass(k, m, H)
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.ctx.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt * 1000.0 / args.steps
+    value = n_k_total / (dt / args.steps)
+
+    if rank == 0:
+        stats = pipe.ctx.kernel_stats()
+        cst = pipe.ctx.count_stats()
+        D = pipe.global_distinct()
+        R = total_reads
+        # ALGORITHMIC bytes: B_alg(read) = 2L + 16(L-20) + 16 D/R + m/(8R)
+        b_alg_read = 2 * L + 16 * (L - 20) + 16.0 * D / R + m / (8.0 * R)
+        b_alg_kmer = b_alg_read / (L - k + 1)
+        # split by stage so a kernel is only credited with the bytes of the stage it implements
+        stage_bytes = pipe.stage_alg_bytes(L, D, R, m)
+        dom_name, dom = max(stats.items(), key=lambda kv: kv[1]["total_ms"]) if stats else ("none", None)
+        roof = None
+        if dom:
+            avg_ms = dom["total_ms"] / dom["launches"]
+            per_launch_bytes = stage_bytes.get(dom_name, 0.0) * (args.reads)  # this rank's reads per launch
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "alg_bytes_per_launch": per_launch_bytes,
+                    "pass_alg_bytes_per_kmer": b_alg_kmer,
+                    "pass_frac": (value / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
+                    "kernels_ms_per_step": {n: s["total_ms"] / args.steps for n, s in sorted(stats.items())}}
+        out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d" % k, "value": value, "unit": "k-mers/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "%d x %d bp synthetic reads per GPU (%d total, 30x, 0.5%% subst), k=%d, "
+                                      "Bloom m=%d bits H=%d (EstimateBloomfilter), count+gate+Bloom+seeds"
+                                      % (args.reads, L, total_reads, k, m, H),
+                          "parallelism": "reads sharded by index x%d" % world,
+                          "distinct_21mers": D, "solid_21mers": cst["n_solid"],
+                          "passing_kmers": pipe.ctx.bloom_stats()["n_passing"]},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, k)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+/* platanus3_amd.h -- C ABI of the MI355X-native k-mer count -> coverage gate -> Bloom build -> seed path.
+ *
+ * This is the drop-in boundary.  The reference (taichimai/platanus3) has no
+ * plugin/FFI interface: the path is reached by direct C++ template calls from Assemble<B>
+ * (reference src/Assemble.cpp:9,12,19,21,24,26).  Each entry point below names the reference
+ * interface it stands in for.  The C++ host shim in platanus3_amd/host/ re-creates the reference's
+ * own call surface (ReadFile::CountShortKmer, MakeBF<B>, BF<B>, ...) on top of this ABI; bench.py and
+ * the parity tests bind it with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every call returns a p3_status (0 = ok); no exceptions
+ * and no callbacks cross the ABI; all exported arrays are caller-allocated; device memory is owned by
+ * the context and released only by p3_destroy; one host thread drives a context at a time (contexts
+ * are independent).  There is NO CPU fallback: without a usable HIP device every compute call fails
+ * with P3_EHIP.
+ *
+ * Keys: a k-mer of 2k bits (21 <= k <= 64) is nw = (2k+63)/64 uint64 words, LOW word first -- the word
+ * order of libstdc++'s std::bitset<2k> that the reference uses as LARGE_BITSET.  Base codes A=0 C=1
+ * G=2 T=3, first base in the most significant used bits (reference src/BitCalc.cpp:7-19).
+ */
+#ifndef PLATANUS3_AMD_H
+#define PLATANUS3_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct p3_ctx p3_ctx;
+
+typedef enum {
+  P3_OK = 0,
+  P3_EBADARG = 1,         /* null pointer, zero size, inconsistent offsets ...            */
+  P3_EUNSUPPORTED_K = 2,  /* k outside [21,64] (the reference silently returns 1: src/Assemble.cpp:51-52) */
+  P3_ECAPACITY = 3,       /* caller buffer too small; the required size is still reported  */
+  P3_EHIP = 4,            /* HIP runtime error / no device (see p3_last_error)             */
+  P3_ECOMM = 5,           /* exchange step misuse (multi-rank protocol)                    */
+  P3_ECOUNT_OVERFLOW = 6, /* a 21-mer count >= 2^31: the reference's RMQ truncates through int
+                             (src/MakeBloomFilter.cpp:11,18); we refuse instead of diverging  */
+  P3_ESTATE = 7,          /* call order violated (e.g. make_bloom before count_short)      */
+  P3_ENOMEM = 8
+} p3_status;
+
+#define P3_SHORTK 21u /* reference: Options::shortk_length default and the constants hard-wired in
+                         src/Load.cpp:106-110 / src/MakeBloomFilter.cpp:27 */
+#define P3_COV_THRESHOLD 2u /* src/MakeBloomFilter.cpp:28 */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* One context drives one HIP device (one process per GPU; multi-GPU = one context per rank plus the
+ * exchange entry points at the end of this header). */
+int p3_create(p3_ctx** out, int device_ordinal);
+int p3_destroy(p3_ctx* ctx);
+const char* p3_last_error(const p3_ctx* ctx);
+int p3_device_count(void);
+/* 1 = record HIP events around every kernel launch (per-kernel stats below); 0 = off (default). */
+int p3_set_profiling(p3_ctx* ctx, int on);
+
+/* ---- T1: reads (reference ReadSet, src/common.h:25, as filled by src/Load.cpp:51-103) ------------ */
+/* Flat form of the ReadSet: concatenated ASCII bases + n_reads+1 offsets.  Reads shorter than
+ * min_len are dropped exactly like the loader does (src/Load.cpp:59,71,86,99 with
+ * large_kmer_length = k), so pass min_len = k to reproduce the reference.  Copies host -> HBM. */
+int p3_load_reads(p3_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len);
+/* Same, but `d_bases`/`d_offsets` are DEVICE pointers already resident in HBM (1 B/base ASCII +
+ * uint64 offsets); nothing is copied -- the buffers must outlive the context's use of them. */
+int p3_load_reads_device(p3_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+                         uint64_t total_bases, uint32_t min_len);
+
+/* ---- C1: ReadFile::CountShortKmer(21) (src/Load.cpp:105-127) -> KmerCount (src/common.h:26) ------- */
+int p3_count_short(p3_ctx* ctx);
+typedef struct {
+  uint64_t n_windows;  /* valid 21-mer windows = increments performed            */
+  uint64_t n_distinct; /* entries of the KmerCount map                           */
+  uint64_t n_solid;    /* entries with count >= P3_COV_THRESHOLD                 */
+  uint64_t max_count;
+} p3_count_stats;
+int p3_get_count_stats(p3_ctx* ctx, p3_count_stats* out);
+/* (key,count) pairs sorted by key; *n = n_distinct even when cap is too small (-> P3_ECAPACITY). */
+int p3_export_counts(p3_ctx* ctx, uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n);
+
+/* ---- G1+G2: MakeBF<bitset<2k>> (src/MakeBloomFilter.cpp:24-89) -> BF<B> + seed set ---------------- */
+/* m_bits/H are what Options::EstimateBloomfilter produced (src/Options.cpp:50-60). */
+int p3_make_bloom(p3_ctx* ctx, uint32_t k, uint64_t m_bits, uint32_t H);
+/* BF::m_bits (src/bloomfilter.cpp:28): ceil(m/64) words, bit i = words[i/64] >> (i%64) & 1. */
+int p3_export_bloom(p3_ctx* ctx, uint64_t* words);
+/* seed set (std::set<std::string>, src/MakeBloomFilter.cpp:79-83) as forward-strand keys, nw words
+ * each, deduplicated and sorted by decoded string (== numeric key order). */
+int p3_export_seeds(p3_ctx* ctx, uint64_t* fwd_keys, uint64_t cap, uint64_t* n);
+typedef struct {
+  uint64_t n_windows_k; /* valid k-mer windows (the metric's unit of work)   */
+  uint64_t n_passing;   /* windows with rmq >= 2 == BF::add calls of the reference */
+  uint64_t n_seed_reads; /* reads that produced a seed (before dedup)          */
+} p3_bloom_stats;
+int p3_get_bloom_stats(p3_ctx* ctx, p3_bloom_stats* out);
+
+/* ---- B2: BF::possiblyContains (src/bloomfilter.cpp:76-86) ---------------------------------------- */
+/* keys: n * nw words (canonical or not -- queried as given, like the reference). out[i] in {0,1}. */
+int p3_bloom_query(p3_ctx* ctx, const uint64_t* keys, uint64_t n, uint8_t* out);
+
+/* ---- convenience: the whole timed pass (C1 + G1 + G2) with results left resident in HBM ---------- */
+int p3_run_pass(p3_ctx* ctx, uint32_t k, uint64_t m_bits, uint32_t H);
+
+/* ---- timings ------------------------------------------------------------------------------------- */
+typedef struct {
+  float ms_pack;   /* ASCII -> 2-bit streams + read-end mask               */
+  float ms_count;  /* C1                                                   */
+  float ms_gate;   /* solid-bit lookup                                     */
+  float ms_bloom;  /* windowed AND + canonical k-mer + hash + bit sets     */
+  float ms_seeds;  /* first passing window per read + dedup                */
+  float ms_total;  /* first event to last event of the most recent pass    */
+} p3_timings;
+int p3_last_timings(p3_ctx* ctx, p3_timings* out);
+/* per-kernel stats accumulated while profiling is on: name (<= 63 chars), launches, total ms.
+ * idx in [0, p3_kernel_stat_count).  p3_reset_kernel_stats clears them. */
+int p3_kernel_stat_count(p3_ctx* ctx);
+int p3_kernel_stat(p3_ctx* ctx, int idx, char* name64, uint64_t* launches, double* total_ms);
+int p3_reset_kernel_stats(p3_ctx* ctx);
+
+/* ---- synthetic workload (plain C, CPU) -------------------------------------- */
+uint64_t p3_synth_genome_length(uint64_t total_reads, uint32_t read_len, uint32_t coverage);
+int p3_synth_reads(uint64_t seed, uint64_t total_reads, uint64_t first_read, uint64_t n_reads,
+                   uint32_t read_len, uint32_t coverage, uint32_t sub_rate_ppm, char* bases, uint64_t* offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLATANUS3_AMD_H */

@@ -42,12 +42,19 @@ def build_lib(force=False, verbose=False):
     srcs, deps = _hip_sources()
     if not (force or _newer(LIB, srcs + deps)):
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
-           "-I" + INCLUDE, "-I" + CSRC, "-o", LIB + ".tmp"] + [s for s in srcs if s.endswith(".hip")]
-    # the plain-C generator is compiled separately (hipcc would treat .c as HIP-less C anyway)
-    obj = os.path.join(CSRC, "p3_synth.o")
-    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-c", "-o", obj, os.path.join(CSRC, "p3_synth.c")])
-    cmd.append(obj)
+    objs = []
+    for src in srcs:
+        obj = os.path.splitext(src)[0] + ".o"
+        if src.endswith(".hip"):
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                   "-I" + INCLUDE, "-I" + CSRC, "-c", "-o", obj, src]
+        else:  # plain C (the synthetic-read generator)
+            cmd = ["gcc", "-O3", "-fPIC", "-I" + INCLUDE, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

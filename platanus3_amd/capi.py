@@ -1,0 +1,212 @@
+"""ctypes binding of include/platanus3_amd.h (libplatanus3_amd.so, built in-tree by _build.build_lib).
+
+There is no CPU fallback: loading fails loudly when the library is missing, and every compute call
+raises P3Error when no HIP device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+P3_OK = 0
+STATUS = {0: "P3_OK", 1: "P3_EBADARG", 2: "P3_EUNSUPPORTED_K", 3: "P3_ECAPACITY", 4: "P3_EHIP", 5: "P3_ECOMM",
+          6: "P3_ECOUNT_OVERFLOW", 7: "P3_ESTATE", 8: "P3_ENOMEM"}
+
+
+class P3Error(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class CountStats(C.Structure):
+    _fields_ = [("n_windows", C.c_uint64), ("n_distinct", C.c_uint64), ("n_solid", C.c_uint64),
+                ("max_count", C.c_uint64)]
+
+
+class BloomStats(C.Structure):
+    _fields_ = [("n_windows_k", C.c_uint64), ("n_passing", C.c_uint64), ("n_seed_reads", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_pack", C.c_float), ("ms_count", C.c_float), ("ms_gate", C.c_float), ("ms_bloom", C.c_float),
+                ("ms_seeds", C.c_float), ("ms_total", C.c_float)]
+
+
+_lib = None
+
+
+def load(build=False):
+    """Returns the loaded C-ABI library.  Raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build:
+        _build.build_lib()
+    if not os.path.exists(_build.LIB):
+        raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)" % _build.LIB)
+    if os.environ.get("P3_NO_TORCH", "0") != "1":
+        try:  # share ONE HIP runtime with torch when both live in this process
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(_build.LIB)
+    vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+    L.p3_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.p3_destroy.argtypes = [vp]
+    L.p3_last_error.restype = C.c_char_p
+    L.p3_last_error.argtypes = [vp]
+    L.p3_device_count.restype = C.c_int
+    L.p3_set_profiling.argtypes = [vp, C.c_int]
+    L.p3_load_reads.argtypes = [vp, vp, vp, u64, u32]
+    L.p3_load_reads_device.argtypes = [vp, vp, vp, u64, u64, u32]
+    L.p3_count_short.argtypes = [vp]
+    L.p3_get_count_stats.argtypes = [vp, C.POINTER(CountStats)]
+    L.p3_export_counts.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.p3_make_bloom.argtypes = [vp, u32, u64, u32]
+    L.p3_export_bloom.argtypes = [vp, vp]
+    L.p3_export_seeds.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.p3_get_bloom_stats.argtypes = [vp, C.POINTER(BloomStats)]
+    L.p3_bloom_query.argtypes = [vp, vp, u64, vp]
+    L.p3_run_pass.argtypes = [vp, u32, u64, u32]
+    L.p3_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.p3_kernel_stat_count.argtypes = [vp]
+    L.p3_kernel_stat.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.p3_reset_kernel_stats.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Every entry point include/platanus3_amd.h declares (used by the CPU-side ABI test)."""
+    import re
+    with open(os.path.join(_build.INCLUDE, "platanus3_amd.h")) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(p3_[a-z0-9_]+)\s*\(", txt)) - {"p3_status"})
+
+
+def nwords(k):
+    return (2 * k + 63) // 64
+
+
+class Context:
+    """One p3_ctx (one HIP device)."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.p3_create(C.byref(h), device)
+        if rc != P3_OK:
+            raise P3Error(rc, "p3_create(device=%d): no usable HIP device?" % device)
+        self.h = h
+        self.k = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.p3_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != P3_OK:
+            raise P3Error(rc, (self.L.p3_last_error(self.h) or b"").decode())
+
+    # ---- T1 -----------------------------------------------------------------------------------------
+    def load_reads(self, bases, offsets, min_len):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._keep = (bases, offsets)
+        self._chk(self.L.p3_load_reads(self.h, bases.ctypes.data, offsets.ctypes.data, offsets.size - 1, min_len))
+
+    def load_reads_device(self, d_bases, d_offsets, n_reads, total_bases, min_len):
+        self._chk(self.L.p3_load_reads_device(self.h, d_bases, d_offsets, n_reads, total_bases, min_len))
+
+    # ---- C1 -----------------------------------------------------------------------------------------
+    def count_short(self):
+        self._chk(self.L.p3_count_short(self.h))
+        return self.count_stats()
+
+    def count_stats(self):
+        s = CountStats()
+        self._chk(self.L.p3_get_count_stats(self.h, C.byref(s)))
+        return dict(n_windows=s.n_windows, n_distinct=s.n_distinct, n_solid=s.n_solid, max_count=s.max_count)
+
+    def export_counts(self):
+        n = C.c_uint64()
+        nd = self.count_stats()["n_distinct"]
+        keys = np.zeros(max(1, nd), np.uint64)
+        counts = np.zeros(max(1, nd), np.uint64)
+        self._chk(self.L.p3_export_counts(self.h, keys.ctypes.data, counts.ctypes.data, keys.size, C.byref(n)))
+        return keys[: n.value], counts[: n.value]
+
+    # ---- G1+G2 --------------------------------------------------------------------------------------
+    def make_bloom(self, k, m, H):
+        self._chk(self.L.p3_make_bloom(self.h, k, m, H))
+        self.k, self.m, self.H = k, m, H
+        return self.bloom_stats()
+
+    def run_pass(self, k, m, H):
+        self._chk(self.L.p3_run_pass(self.h, k, m, H))
+        self.k, self.m, self.H = k, m, H
+
+    def bloom_stats(self):
+        s = BloomStats()
+        self._chk(self.L.p3_get_bloom_stats(self.h, C.byref(s)))
+        return dict(n_windows_k=s.n_windows_k, n_passing=s.n_passing, n_seed_reads=s.n_seed_reads)
+
+    def export_bloom(self):
+        words = np.zeros((self.m + 63) // 64, np.uint64)
+        self._chk(self.L.p3_export_bloom(self.h, words.ctypes.data))
+        return words
+
+    def export_seeds(self, cap=None):
+        nw = nwords(self.k)
+        n = C.c_uint64()
+        cap = cap if cap is not None else max(1, self.bloom_stats()["n_seed_reads"])
+        out = np.zeros(cap * nw, np.uint64)
+        self._chk(self.L.p3_export_seeds(self.h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value * nw].reshape(n.value, nw)
+
+    def bloom_query(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64).reshape(-1)
+        n = keys.size // nwords(self.k)
+        out = np.zeros(max(1, n), np.uint8)
+        self._chk(self.L.p3_bloom_query(self.h, keys.ctypes.data, n, out.ctypes.data))
+        return out[:n]
+
+    # ---- timings ------------------------------------------------------------------------------------
+    def set_profiling(self, on):
+        self._chk(self.L.p3_set_profiling(self.h, 1 if on else 0))
+
+    def timings(self):
+        t = Timings()
+        self._chk(self.L.p3_last_timings(self.h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timings._fields_}
+
+    def kernel_stats(self):
+        out = {}
+        for i in range(self.L.p3_kernel_stat_count(self.h)):
+            name = C.create_string_buffer(64)
+            n, ms = C.c_uint64(), C.c_double()
+            self._chk(self.L.p3_kernel_stat(self.h, i, name, C.byref(n), C.byref(ms)))
+            out[name.value.decode()] = dict(launches=n.value, total_ms=ms.value)
+        return out
+
+    def reset_kernel_stats(self):
+        self._chk(self.L.p3_reset_kernel_stats(self.h))
+
+
+def decode_key(words, k):
+    """Key words (low word first) -> ACGT string (reference GetStringKmer, src/BitCalc.cpp:56-65)."""
+    v = 0
+    for i, w in enumerate(words):
+        v |= int(w) << (64 * i)
+    return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))

@@ -1,0 +1,552 @@
+// p3_lib.hip -- context management and the C ABI of include/platanus3_amd.h (gfx950 only).
+//
+// Host-side orchestration of the HIP kernels in p3_kernels.h.  No CPU compute fallback exists: every
+// stage runs on the device or the call fails with P3_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "platanus3_amd.h"
+#include "p3_kernels.h"
+
+namespace {
+
+struct KStat {
+  std::string name;
+  uint64_t launches = 0;
+  double ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct p3_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  std::vector<KStat> kstats;
+
+  // reads
+  const uint8_t* d_bases = nullptr;  // may alias owned_bases.p or caller memory
+  const u64* d_offsets = nullptr;
+  DevBuf owned_bases, owned_offsets;
+  u64 n_reads = 0, n_bases = 0, n_words = 0;
+  u32 min_len = 0;
+  bool have_reads = false;
+
+  // packed streams
+  DevBuf fw, rcw, endm, S, P;
+  bool packed = false;
+
+  // count table (direct) + compact export form
+  DevBuf tkeys, tcounts, ckeys, ccounts, dstats;
+  u64 cap = 0;
+  bool counted = false;
+  p3_count_stats cstats{};
+
+  // bloom
+  DevBuf bloom, seeds;
+  u32 k = 0, H = 0;
+  u64 m = 0;
+  bool bloomed = false;
+  p3_bloom_stats bstats{};
+
+  hipEvent_t ev[8] = {};
+  p3_timings tm{};
+};
+
+namespace {
+
+int fail(p3_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return fail((c), P3_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                           \
+  } while (0)
+
+int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes && b.p) return P3_OK;
+  if (b.p) {
+    HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(c, e == hipErrorOutOfMemory ? P3_ENOMEM : P3_EHIP, "hipMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  b.bytes = bytes ? bytes : 16;
+  return P3_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+KStat* stat_for(p3_ctx* c, const char* name) {
+  for (auto& s : c->kstats)
+    if (s.name == name) return &s;
+  c->kstats.emplace_back();
+  c->kstats.back().name = name;
+  return &c->kstats.back();
+}
+
+int drain_stats(p3_ctx* c) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& s : c->kstats) {
+    for (auto& pr : s.pending) {
+      float ms = 0;
+      HIPCHK(c, hipEventElapsedTime(&ms, pr.first, pr.second));
+      s.ms += ms;
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    s.pending.clear();
+  }
+  return P3_OK;
+}
+
+// Launch helper: optional per-kernel HIP-event bracketing on the context's stream.
+#define LAUNCH(c, name, kernel, grid, block, ...)                                          \
+  do {                                                                                     \
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;                                               \
+    if ((c)->profiling) {                                                                  \
+      HIPCHK(c, hipEventCreate(&e0_));                                                     \
+      HIPCHK(c, hipEventCreate(&e1_));                                                     \
+      HIPCHK(c, hipEventRecord(e0_, (c)->stream));                                         \
+    }                                                                                      \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);      \
+    HIPCHK(c, hipGetLastError());                                                          \
+    if ((c)->profiling) {                                                                  \
+      HIPCHK(c, hipEventRecord(e1_, (c)->stream));                                         \
+      KStat* s_ = stat_for(c, name);                                                       \
+      s_->launches++;                                                                      \
+      s_->pending.push_back({e0_, e1_});                                                   \
+    }                                                                                      \
+  } while (0)
+
+inline unsigned grid_for(u64 items, unsigned block = 256, unsigned max_blocks = 256 * 16) {
+  u64 g = (items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (unsigned)g;
+}
+
+ModM make_modm(u64 m) {
+  ModM mm;
+  mm.m = m;
+  if (m == 1) {
+    mm.M = ~0ULL;
+    mm.c = 0;
+  } else {
+    unsigned __int128 two64 = (unsigned __int128)1 << 64;
+    mm.M = (u64)(two64 / m);
+    mm.c = (u64)(two64 % m);
+  }
+  return mm;
+}
+
+inline int nw_of(u32 k) { return (2 * k + 63) / 64; }
+
+int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
+  c->n_reads = n_reads;
+  c->n_bases = n_bases;
+  c->n_words = (n_bases + 31) / 32;
+  c->min_len = min_len;
+  c->have_reads = true;
+  c->packed = c->counted = c->bloomed = false;
+  return P3_OK;
+}
+
+// ASCII -> packed streams + read-end mask (inside the timed pass: this IS the BitCalc encode step)
+int do_pack(p3_ctx* c) {
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  int rc;
+  if ((rc = ensure(c, c->fw, nwa * 8))) return rc;
+  if ((rc = ensure(c, c->rcw, nwa * 8))) return rc;
+  if ((rc = ensure(c, c->endm, nwa * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->endm.p, 0, nwa * 4, c->stream));
+  const int aligned = (((uintptr_t)c->d_bases) & 15) == 0;
+  LAUNCH(c, "k_pack", k_pack, grid_for(nwa), 256, c->d_bases, c->n_bases, nwa, (u64*)c->fw.p, (u64*)c->rcw.p, aligned);
+  LAUNCH(c, "k_endmask", k_endmask, grid_for(c->n_reads + 1), 256, c->d_offsets, c->n_reads, c->min_len,
+         (u32*)c->endm.p, c->n_bases, nwa * 32);
+  c->packed = true;
+  return P3_OK;
+}
+
+int do_count(p3_ctx* c) {
+  int rc;
+  // direct table: capacity = pow2 >= 1.5 * (upper bound on distinct keys = number of bases)
+  u64 want = c->n_bases + c->n_bases / 2 + 1024;
+  u64 cap = 1024;
+  while (cap < want) cap <<= 1;
+  c->cap = cap;
+  if ((rc = ensure(c, c->tkeys, cap * 8))) return rc;
+  if ((rc = ensure(c, c->tcounts, cap * 8))) return rc;
+  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->tkeys.p, 0xff, cap * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->tcounts.p, 0, cap * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
+  u64* st = (u64*)c->dstats.p;
+  LAUNCH(c, "k_count_direct", k_count_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, c->n_words, (u64*)c->tkeys.p, (u64*)c->tcounts.p, cap - 1, st + 3);
+  // compact (key,count) list: at most min(cap, n_bases) entries
+  u64 maxd = c->n_bases + 1;
+  if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
+  LAUNCH(c, "k_count_compact", k_count_compact, grid_for(cap), 256, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p,
+         cap, (u64*)c->ckeys.p, (u64*)c->ccounts.p, st);
+  u64 h[4];
+  HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->cstats.n_distinct = h[0];
+  c->cstats.n_solid = h[1];
+  c->cstats.max_count = h[2];
+  c->cstats.n_windows = h[3];
+  c->counted = true;
+  return P3_OK;
+}
+
+template <int NW>
+int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
+  int rc;
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  const u64 bwords = (m + 63) / 64;
+  if ((rc = ensure(c, c->S, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->P, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->bloom, bwords * 8))) return rc;
+  if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  LAUNCH(c, "k_gate_direct", k_gate_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, c->n_words, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p, c->cap - 1, (u32*)c->S.p);
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  const ModM mm = make_modm(m);
+  LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
+         (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p,
+         (u32*)c->P.p, st + 8);
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads), 256, c->d_offsets, c->n_reads, c->min_len, k,
+         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, st + 10);
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  u64 h[3];
+  HIPCHK(c, hipMemcpyAsync(h, st + 8, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bstats.n_windows_k = h[0];
+  c->bstats.n_passing = h[1];
+  c->bstats.n_seed_reads = h[2];
+  c->k = k;
+  c->m = m;
+  c->H = H;
+  c->bloomed = true;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_gate = ms;
+  if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->tm.ms_bloom = ms;
+  if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_seeds = ms;
+  return P3_OK;
+}
+
+int check_k(p3_ctx* c, u32 k) {
+  if (k < 21 || k > 64) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,64]", k);
+  return P3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int p3_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int p3_create(p3_ctx** out, int device_ordinal) {
+  if (!out) return P3_EBADARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n) return P3_EHIP;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return P3_EHIP;
+  p3_ctx* c = new p3_ctx();
+  c->device = device_ordinal;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return P3_EHIP;
+  }
+  for (auto& ev : c->ev)
+    if (hipEventCreate(&ev) != hipSuccess) {
+      delete c;
+      return P3_EHIP;
+    }
+  *out = c;
+  return P3_OK;
+}
+
+int p3_destroy(p3_ctx* c) {
+  if (!c) return P3_EBADARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->kstats)
+    for (auto& pr : s.pending) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
+                    &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds};
+  for (DevBuf* b : bufs) release(*b);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return P3_OK;
+}
+
+const char* p3_last_error(const p3_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int p3_set_profiling(p3_ctx* c, int on) {
+  if (!c) return P3_EBADARG;
+  c->profiling = on != 0;
+  return P3_OK;
+}
+
+int p3_load_reads(p3_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len) {
+  if (!c) return P3_EBADARG;
+  if (!offsets || (n_reads && !bases)) return fail(c, P3_EBADARG, "null bases/offsets");
+  for (u64 i = 0; i < n_reads; i++)
+    if (offsets[i + 1] < offsets[i]) return fail(c, P3_EBADARG, "offsets not monotonic at read %llu", (unsigned long long)i);
+  HIPCHK(c, hipSetDevice(c->device));
+  const u64 off0 = offsets[0];
+  const u64 n_bases = offsets[n_reads] - off0;
+  int rc;
+  if ((rc = ensure(c, c->owned_bases, n_bases + 64))) return rc;
+  if ((rc = ensure(c, c->owned_offsets, (n_reads + 1) * 8))) return rc;
+  if (n_bases) HIPCHK(c, hipMemcpyAsync(c->owned_bases.p, bases + off0, n_bases, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->owned_offsets.p, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->d_bases = (const uint8_t*)c->owned_bases.p;
+  c->d_offsets = (const u64*)c->owned_offsets.p;
+  return set_reads_common(c, n_reads, n_bases, min_len);
+}
+
+int p3_load_reads_device(p3_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+                         uint64_t total_bases, uint32_t min_len) {
+  if (!c) return P3_EBADARG;
+  if (!d_offsets || (total_bases && !d_bases)) return fail(c, P3_EBADARG, "null device pointers");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->d_bases = (const uint8_t*)d_bases;
+  c->d_offsets = (const u64*)d_offsets;
+  return set_reads_common(c, n_reads, total_bases, min_len);
+}
+
+int p3_count_short(p3_ctx* c) {
+  if (!c) return P3_EBADARG;
+  if (!c->have_reads) return fail(c, P3_ESTATE, "p3_count_short before p3_load_reads");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if ((rc = do_pack(c))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if ((rc = do_count(c))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_pack = ms;
+  if (hipEventElapsedTime(&ms, c->ev[1], c->ev[6]) == hipSuccess) c->tm.ms_count = ms;
+  return P3_OK;
+}
+
+int p3_get_count_stats(p3_ctx* c, p3_count_stats* out) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->counted) return fail(c, P3_ESTATE, "no count table yet");
+  *out = c->cstats;
+  return P3_OK;
+}
+
+int p3_export_counts(p3_ctx* c, uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->counted) return fail(c, P3_ESTATE, "no count table yet");
+  const u64 nd = c->cstats.n_distinct;
+  *n = nd;
+  if (cap < nd) return fail(c, P3_ECAPACITY, "need %llu entries", (unsigned long long)nd);
+  if (nd == 0) return P3_OK;
+  if (!keys || !counts) return fail(c, P3_EBADARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<std::pair<u64, u64>> v(nd);
+  {
+    std::vector<u64> hk(nd), hc(nd);
+    HIPCHK(c, hipMemcpy(hk.data(), c->ckeys.p, nd * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hc.data(), c->ccounts.p, nd * 8, hipMemcpyDeviceToHost));
+    for (u64 i = 0; i < nd; i++) v[i] = {hk[i], hc[i]};
+  }
+  std::sort(v.begin(), v.end());
+  for (u64 i = 0; i < nd; i++) {
+    keys[i] = v[i].first;
+    counts[i] = v[i].second;
+  }
+  return P3_OK;
+}
+
+int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
+  if (!c) return P3_EBADARG;
+  int rc;
+  if ((rc = check_k(c, k))) return rc;
+  if (m_bits == 0 || m_bits >= (1ULL << 62) || H > 255) return fail(c, P3_EBADARG, "bad Bloom parameters m=%llu H=%u",
+                                                                    (unsigned long long)m_bits, H);
+  if (!c->counted) return fail(c, P3_ESTATE, "p3_make_bloom before p3_count_short");
+  if (c->cstats.max_count >= (1ULL << 31))
+    return fail(c, P3_ECOUNT_OVERFLOW, "a 21-mer count (%llu) >= 2^31: reference RMQ would truncate",
+                (unsigned long long)c->cstats.max_count);
+  HIPCHK(c, hipSetDevice(c->device));
+  return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+}
+
+int p3_get_bloom_stats(p3_ctx* c, p3_bloom_stats* out) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "no Bloom filter yet");
+  *out = c->bstats;
+  return P3_OK;
+}
+
+int p3_export_bloom(p3_ctx* c, uint64_t* words) {
+  if (!c || !words) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "no Bloom filter yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  const u64 bwords = (c->m + 63) / 64;
+  HIPCHK(c, hipMemcpy(words, c->bloom.p, bwords * 8, hipMemcpyDeviceToHost));
+  return P3_OK;
+}
+
+int p3_export_seeds(p3_ctx* c, uint64_t* fwd_keys, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "no seeds yet");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nw = nw_of(c->k);
+  std::vector<u64> h((size_t)c->n_reads * nw);
+  if (c->n_reads) HIPCHK(c, hipMemcpy(h.data(), c->seeds.p, h.size() * 8, hipMemcpyDeviceToHost));
+  // std::set<std::string> semantics: sort + unique.  String order == numeric order of the key.
+  std::vector<std::pair<u64, u64>> v;  // (hi, lo)
+  v.reserve(c->n_reads);
+  for (u64 r = 0; r < c->n_reads; r++) {
+    u64 lo = h[r * nw], hi = nw == 2 ? h[r * nw + 1] : 0;
+    if (lo == P3_EMPTY_KEY && (nw == 1 || hi == P3_EMPTY_KEY)) continue;
+    v.push_back({hi, lo});
+  }
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  *n = v.size();
+  if (cap < v.size()) return fail(c, P3_ECAPACITY, "need %zu seed slots", v.size());
+  if (v.size() && !fwd_keys) return fail(c, P3_EBADARG, "null output");
+  for (size_t i = 0; i < v.size(); i++) {
+    fwd_keys[i * nw] = v[i].second;
+    if (nw == 2) fwd_keys[i * nw + 1] = v[i].first;
+  }
+  return P3_OK;
+}
+
+int p3_bloom_query(p3_ctx* c, const uint64_t* keys, uint64_t n, uint8_t* out) {
+  if (!c) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "no Bloom filter yet");
+  if (n == 0) return P3_OK;
+  if (!keys || !out) return fail(c, P3_EBADARG, "null keys/out");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nw = nw_of(c->k);
+  DevBuf dk, dout;
+  int rc;
+  if ((rc = ensure(c, dk, n * nw * 8))) return rc;
+  if ((rc = ensure(c, dout, n))) {
+    release(dk);
+    return rc;
+  }
+  const ModM mm = make_modm(c->m);
+  hipError_t e = hipMemcpyAsync(dk.p, keys, n * nw * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    if (nw == 1)
+      hipLaunchKernelGGL((k_bloom_query<1>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
+                         c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
+    else
+      hipLaunchKernelGGL((k_bloom_query<2>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
+                         c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout.p, n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  release(dk);
+  release(dout);
+  if (e != hipSuccess) return fail(c, P3_EHIP, "bloom_query: %s", hipGetErrorString(e));
+  return P3_OK;
+}
+
+int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
+  int rc;
+  if ((rc = p3_count_short(c))) return rc;
+  if ((rc = p3_make_bloom(c, k, m_bits, H))) return rc;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
+  return P3_OK;
+}
+
+int p3_last_timings(p3_ctx* c, p3_timings* out) {
+  if (!c || !out) return P3_EBADARG;
+  *out = c->tm;
+  return P3_OK;
+}
+
+int p3_kernel_stat_count(p3_ctx* c) {
+  if (!c) return 0;
+  if (drain_stats(c) != P3_OK) return 0;
+  return (int)c->kstats.size();
+}
+
+int p3_kernel_stat(p3_ctx* c, int idx, char* name64, uint64_t* launches, double* total_ms) {
+  if (!c || idx < 0 || idx >= (int)c->kstats.size()) return P3_EBADARG;
+  int rc = drain_stats(c);
+  if (rc) return rc;
+  const KStat& s = c->kstats[idx];
+  if (name64) {
+    std::strncpy(name64, s.name.c_str(), 63);
+    name64[63] = 0;
+  }
+  if (launches) *launches = s.launches;
+  if (total_ms) *total_ms = s.ms;
+  return P3_OK;
+}
+
+int p3_reset_kernel_stats(p3_ctx* c) {
+  if (!c) return P3_EBADARG;
+  int rc = drain_stats(c);
+  c->kstats.clear();
+  return rc;
+}
+
+}  // extern "C"
