@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(256) k_bloom_direct(const u64* __restrict__ fw
 template <int NW>
 __global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, u64 n_reads, u32 min_len, u32 k,
                                                const u32* __restrict__ P, const u64* __restrict__ fw,
-                                               u64* __restrict__ seed_keys, u64* __restrict__ n_seed_reads) {
+                                               u64* __restrict__ seed_keys, uint8_t* __restrict__ seed_valid,
+                                               u64* __restrict__ n_seed_reads) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
   u64 local = 0;
   for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
@@ -319,13 +320,11 @@ __global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, 
         seed_keys[2 * r] = lo;
         seed_keys[2 * r + 1] = hi;
       }
+      seed_valid[r] = 1;
       local++;
     } else {
-      if (NW == 1) seed_keys[r] = P3_EMPTY_KEY;
-      else {
-        seed_keys[2 * r] = P3_EMPTY_KEY;
-        seed_keys[2 * r + 1] = P3_EMPTY_KEY;
-      }
+      // (an all-T 32-/64-mer is the all-ones key, so validity needs its own flag)
+      seed_valid[r] = 0;
     }
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);

@@ -57,7 +57,7 @@ struct p3_ctx {
   p3_count_stats cstats{};
 
   // bloom
-  DevBuf bloom, seeds;
+  DevBuf bloom, seeds, seed_valid;
   u32 k = 0, H = 0;
   u64 m = 0;
   bool bloomed = false;
@@ -242,6 +242,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if ((rc = ensure(c, c->P, nwa * 4))) return rc;
   if ((rc = ensure(c, c->bloom, bwords * 8))) return rc;
   if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->seed_valid, c->n_reads + 1))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
@@ -257,7 +258,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
          (u32*)c->P.p, st + 8);
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads), 256, c->d_offsets, c->n_reads, c->min_len, k,
-         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, st + 10);
+         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 h[3];
   HIPCHK(c, hipMemcpyAsync(h, st + 8, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -323,7 +324,7 @@ int p3_destroy(p3_ctx* c) {
       (void)hipEventDestroy(pr.second);
     }
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
-                    &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds};
+                    &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -453,13 +454,17 @@ int p3_export_seeds(p3_ctx* c, uint64_t* fwd_keys, uint64_t cap, uint64_t* n) {
   HIPCHK(c, hipSetDevice(c->device));
   const int nw = nw_of(c->k);
   std::vector<u64> h((size_t)c->n_reads * nw);
-  if (c->n_reads) HIPCHK(c, hipMemcpy(h.data(), c->seeds.p, h.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> hv((size_t)c->n_reads);
+  if (c->n_reads) {
+    HIPCHK(c, hipMemcpy(h.data(), c->seeds.p, h.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hv.data(), c->seed_valid.p, hv.size(), hipMemcpyDeviceToHost));
+  }
   // std::set<std::string> semantics: sort + unique.  String order == numeric order of the key.
   std::vector<std::pair<u64, u64>> v;  // (hi, lo)
   v.reserve(c->n_reads);
   for (u64 r = 0; r < c->n_reads; r++) {
+    if (!hv[r]) continue;
     u64 lo = h[r * nw], hi = nw == 2 ? h[r * nw + 1] : 0;
-    if (lo == P3_EMPTY_KEY && (nw == 1 || hi == P3_EMPTY_KEY)) continue;
     v.push_back({hi, lo});
   }
   std::sort(v.begin(), v.end());
