@@ -55,6 +55,15 @@ int p3_device_count(void);
 /* 1 = record HIP events around every kernel launch (per-kernel stats below); 0 = off (default). */
 int p3_set_profiling(p3_ctx* ctx, int on);
 
+/* Tuning / test knobs (not needed for normal use):
+ *   "count_mode"  0 = auto (partitioned LDS count when the input fits, else direct), 1 = force the direct
+ *                 global-table kernels, 2 = force the partitioned kernels (error if they cannot be used)
+ *   "ts_log2"     log2 of the LDS count-table slots per sub-bucket (<= 14); small values force the
+ *                 overflow -> re-split -> direct fallback chain in tests
+ * p3_get_info reads back "count_mode" (path the last count used), "sbits", "rs_log2". */
+int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
+int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
+
 /* ---- T1: reads (reference ReadSet, src/common.h:25, as filled by src/Load.cpp:51-103) ------------ */
 /* Flat form of the ReadSet: concatenated ASCII bases + n_reads+1 offsets.  Reads shorter than
  * min_len are dropped exactly like the loader does (src/Load.cpp:59,71,86,99 with

@@ -61,6 +61,8 @@ def load(build=False):
     L.p3_last_error.argtypes = [vp]
     L.p3_device_count.restype = C.c_int
     L.p3_set_profiling.argtypes = [vp, C.c_int]
+    L.p3_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.p3_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.p3_load_reads.argtypes = [vp, vp, vp, u64, u32]
     L.p3_load_reads_device.argtypes = [vp, vp, vp, u64, u64, u32]
     L.p3_count_short.argtypes = [vp]
@@ -118,6 +120,14 @@ class Context:
     def _chk(self, rc):
         if rc != P3_OK:
             raise P3Error(rc, (self.L.p3_last_error(self.h) or b"").decode())
+
+    def set_option(self, name, value):
+        self._chk(self.L.p3_set_option(self.h, name.encode(), value))
+
+    def get_info(self, name):
+        v = C.c_int64()
+        self._chk(self.L.p3_get_info(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     # ---- T1 -----------------------------------------------------------------------------------------
     def load_reads(self, bases, offsets, min_len):

@@ -1,0 +1,422 @@
+// p3_kernels_part.h -- the partitioned (LDS-resident) form of the count stage and of the gate lookup.
+//
+// Replaces the global-atomics "direct" kernels on inputs that fit its limits (everything BASELINE
+// config #2-sized; larger inputs and LDS-table overflows fall back to the direct kernels):
+//
+//   k_part_hist     canonical 21-mer of every valid window -> bijective 42-bit mix g -> bucket histogram
+//                   per (workgroup, bucket); nothing else is written                 (C1, src/Load.cpp:113-125)
+//   k_part_scan     exact, 64-byte aligned segment offsets for every (bucket, workgroup) pair
+//   k_part_scatter  same enumeration; the low 32 bits of g are staged per bucket in LDS and flushed as
+//                   whole 64-byte chunks into the (bucket, workgroup) segment -- no global atomics
+//   k_part_count    one workgroup per sub-bucket: LDS open-addressing table (key remainder, count),
+//                   then compact (key,count) emission = the KmerCount map            (src/common.h:26)
+//   k_solid_regions per sub-bucket table of the solid (count >= 2) remainders, built in LDS, stored whole
+//   k_gate_regions  shortk_cov[j] >= 2 as one probe of the solid table   (src/MakeBloomFilter.cpp:52-58,75)
+//
+// Quotienting: g is a bijection on [0,2^42), so (bucket, sub-bucket, remainder) identifies the key and
+// a partition record is 4 bytes instead of 8.
+#pragma once
+#include "p3_kernels.h"
+
+#define P3_PBITS 10
+#define P3_NB (1u << P3_PBITS)  // physical buckets
+#define P3_CAP 32u              // staged records per bucket (two 64-byte chunks)
+#define P3_NWG 256u             // workgroups of the hist/scatter kernels (static word partition)
+#define P3_PART_THREADS 1024
+#define P3_TS_LOG2_MAX 14       // LDS count table: 16384 slots x (4 B remainder + 4 B count) = 128 KiB
+#define P3_EMPTY32 0xffffffffu
+#define P3_MIX_C 0x1E3779B97F5ULL  // odd, < 2^42
+#define P3_MASK42 ((1ULL << 42) - 1)
+
+__host__ __device__ constexpr u64 p3_modinv64(u64 a) {
+  u64 x = a;  // Newton: doubles the number of correct low bits each step (a odd)
+  for (int i = 0; i < 6; i++) x *= 2 - a * x;
+  return x;
+}
+#define P3_MIX_CINV (p3_modinv64(P3_MIX_C) & P3_MASK42)
+
+__host__ __device__ __forceinline__ u64 mix42(u64 x) {
+  x ^= x >> 21;
+  return (x * P3_MIX_C) & P3_MASK42;
+}
+__host__ __device__ __forceinline__ u64 unmix42(u64 g) {
+  u64 x = (g * P3_MIX_CINV) & P3_MASK42;
+  return x ^ (x >> 21);
+}
+
+// words [wg_begin, wg_end) of workgroup `wg`: equal contiguous shares, multiples of the block size
+__device__ __forceinline__ void part_word_range(u64 n_words, u32 wg, u64& begin, u64& end) {
+  u64 per = (n_words + P3_NWG - 1) / P3_NWG;
+  per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+  begin = (u64)wg * per;
+  end = begin + per;
+  if (begin > n_words) begin = n_words;
+  if (end > n_words) end = n_words;
+}
+
+// ---- k_part_hist -------------------------------------------------------------------------------------
+// ghist[pb * P3_NWG + wg] = number of records workgroup wg will send to bucket pb
+__global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+                                                               const u32* __restrict__ endm, u64 n_words,
+                                                               u32* __restrict__ ghist) {
+  __shared__ u32 hist[P3_NB];
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  u64 begin, end;
+  part_word_range(n_words, blockIdx.x, begin, end);
+  for (u64 w = begin + threadIdx.x; w < end; w += blockDim.x) {
+    LaneWords L = load_lane_words(fw, rcw, endm, w);
+    KmerRoll<1> kr;
+    kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+    const u64 vmask = (1ULL << 20) - 1;
+#pragma unroll 4
+    for (int j = 0; j < 32; j++) {
+      if ((L.Elo & vmask) == 0) {
+        u64 lo, hi;
+        kr.canonical(lo, hi);
+        atomicAdd(&hist[(u32)(mix42(lo) >> 32)], 1u);
+      }
+      kr.roll();
+      shr128(L.Elo, L.Ehi);
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
+}
+
+// ---- k_part_scan: one workgroup, thread pb owns bucket pb ----------------------------------------------
+// seg_off[pb*NWG + wg] = first record index of segment (pb,wg); every segment starts on a multiple of 16
+// records (64 bytes).  totals[0] = valid windows, totals[1] = padded records, totals[2] = largest bucket
+__global__ void __launch_bounds__(P3_NB) k_part_scan(const u32* __restrict__ ghist, u32* __restrict__ seg_off,
+                                                     u32* __restrict__ bucket_count, u64* __restrict__ totals) {
+  __shared__ u32 padded[P3_NB];
+  __shared__ u32 base[P3_NB];
+  const u32 pb = threadIdx.x;
+  u32 run = 0, exact = 0;
+  for (u32 wg = 0; wg < P3_NWG; wg++) {
+    u32 c = ghist[pb * P3_NWG + wg];
+    exact += c;
+    run += (c + 15u) & ~15u;
+  }
+  padded[pb] = run;
+  bucket_count[pb] = exact;
+  __syncthreads();
+  if (pb == 0) {
+    u64 acc = 0;
+    for (u32 i = 0; i < P3_NB; i++) {
+      base[i] = (u32)acc;
+      acc += padded[i];
+    }
+    totals[1] = acc;
+  }
+  __syncthreads();
+  run = base[pb];
+  for (u32 wg = 0; wg < P3_NWG; wg++) {
+    u32 c = ghist[pb * P3_NWG + wg];
+    seg_off[pb * P3_NWG + wg] = run;
+    run += (c + 15u) & ~15u;
+  }
+  // totals[0], totals[2] via atomics (1024 threads, once)
+  atomicAdd((unsigned long long*)&totals[0], (unsigned long long)exact);
+  atomicMax((unsigned long long*)&totals[2], (unsigned long long)exact);
+}
+
+// ---- k_part_scatter ------------------------------------------------------------------------------------
+// LDS: stage[NB][CAP] records, cnt[NB] staged-record tickets, wpos[NB] records already flushed into the
+// (bucket, this workgroup) segment, segb[NB] segment base.  Rounds of 8 windows per lane keep the inflow
+// per bucket (~8) well under CAP; a record that finds its bucket full waits for the next flush.
+__device__ __forceinline__ void part_flush(u32* stage, u32* cnt, u32* wpos, const u32* segb, u32* __restrict__ part,
+                                           bool final_flush) {
+  const u32 q = threadIdx.x & 3;
+  for (u32 it = 0; it < P3_NB / (P3_PART_THREADS / 4); it++) {
+    const u32 b = it * (P3_PART_THREADS / 4) + (threadIdx.x >> 2);
+    u32 n = cnt[b];
+    n = n < P3_CAP ? n : P3_CAP;
+    u32 nfl = n & ~15u;
+    if (final_flush && (n & 15u)) nfl = (n + 15u) & ~15u;  // segment is padded: a whole last chunk is fine
+    if (nfl) {
+      const u32 dst = segb[b] + wpos[b];
+      uint4 v = *reinterpret_cast<const uint4*>(&stage[b * P3_CAP + 4 * q]);
+      *reinterpret_cast<uint4*>(&part[dst + 4 * q]) = v;
+      if (nfl == 32) {
+        uint4 v2 = *reinterpret_cast<const uint4*>(&stage[b * P3_CAP + 16 + 4 * q]);
+        *reinterpret_cast<uint4*>(&part[dst + 16 + 4 * q]) = v2;
+      }
+    }
+    if (!final_flush) {
+      const u32 r = n - nfl;  // < 16 records stay; they move to the front (src >= 16 > dst: no overlap)
+      u32 m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+      if (nfl) {
+        if (q < r) m0 = stage[b * P3_CAP + nfl + q];
+        if (q + 4 < r) m1 = stage[b * P3_CAP + nfl + q + 4];
+        if (q + 8 < r) m2 = stage[b * P3_CAP + nfl + q + 8];
+        if (q + 12 < r) m3 = stage[b * P3_CAP + nfl + q + 12];
+        if (q < r) stage[b * P3_CAP + q] = m0;
+        if (q + 4 < r) stage[b * P3_CAP + q + 4] = m1;
+        if (q + 8 < r) stage[b * P3_CAP + q + 8] = m2;
+        if (q + 12 < r) stage[b * P3_CAP + q + 12] = m3;
+      }
+      if (q == 0) {
+        cnt[b] = r;
+        wpos[b] += nfl;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+                                                                  const u32* __restrict__ endm, u64 n_words,
+                                                                  const u32* __restrict__ seg_off,
+                                                                  u32* __restrict__ part) {
+  extern __shared__ __align__(16) u32 lds[];
+  u32* stage = lds;                       // NB * CAP
+  u32* cnt = stage + P3_NB * P3_CAP;      // NB
+  u32* wpos = cnt + P3_NB;                // NB
+  u32* segb = wpos + P3_NB;               // NB
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+    cnt[i] = 0;
+    wpos[i] = 0;
+    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+  }
+  __syncthreads();
+  u64 begin, end;
+  part_word_range(n_words, blockIdx.x, begin, end);
+  for (u64 base = begin; base < end; base += blockDim.x) {
+    const u64 w = base + threadIdx.x;
+    const bool active = w < end;
+    LaneWords L;
+    KmerRoll<1> kr;
+    if (active) {
+      L = load_lane_words(fw, rcw, endm, w);
+      kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+    } else {
+      L.Elo = ~0ULL;
+      L.Ehi = ~0ULL;
+    }
+    const u64 vmask = (1ULL << 20) - 1;
+    for (int chunk = 0; chunk < 4; chunk++) {
+      u32 rec[8], pbk[8];
+      u32 pend = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        rec[i] = 0;
+        pbk[i] = 0;
+        if (active && (L.Elo & vmask) == 0) {
+          u64 lo, hi;
+          kr.canonical(lo, hi);
+          const u64 g = mix42(lo);
+          rec[i] = (u32)g;
+          pbk[i] = (u32)(g >> 32);
+          pend |= 1u << i;
+        }
+        if (active) {
+          kr.roll();
+          shr128(L.Elo, L.Ehi);
+        }
+      }
+      int more;
+      do {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (pend & (1u << i)) {
+            const u32 pos = atomicAdd(&cnt[pbk[i]], 1u);
+            if (pos < P3_CAP) {
+              stage[pbk[i] * P3_CAP + pos] = rec[i];
+              pend &= ~(1u << i);
+            }
+          }
+        }
+        __syncthreads();
+        part_flush(stage, cnt, wpos, segb, part, false);
+        more = __syncthreads_or(pend != 0);
+      } while (more);
+    }
+  }
+  part_flush(stage, cnt, wpos, segb, part, true);
+}
+
+// ---- k_part_count: one workgroup per sub-bucket ---------------------------------------------------------
+// gstats[0] = distinct cursor, [1] = solid total, [2] = max count, [3] = overflow flag, [4] = max solid per
+// sub-bucket.  sb_info[sb] = {base, n_distinct, n_solid, 0}
+__global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+                                                     const u32* __restrict__ ghist, u32 sbits, u32 ts_log2,
+                                                     u64* __restrict__ out_keys, u32* __restrict__ out_counts,
+                                                     uint4* __restrict__ sb_info, u64* __restrict__ gstats) {
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 TS = 1u << ts_log2;
+  u32* tkey = lds;
+  u32* tcnt = lds + TS;
+  u32* sc = lds + 2 * TS;  // scalars live behind the table so the dynamic region keeps its alignment
+#define s_ndist sc[0]
+#define s_cur sc[1]
+#define s_base_lo sc[2]
+#define s_base_hi sc[3]
+#define s_nsolid sc[4]
+#define s_max sc[5]
+#define s_ovf sc[6]
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+    tkey[i] = P3_EMPTY32;
+    tcnt[i] = 0;
+  }
+  if (threadIdx.x == 0) {
+    s_ndist = 0;
+    s_cur = 0;
+    s_nsolid = 0;
+    s_max = 0;
+    s_ovf = 0;
+  }
+  __syncthreads();
+  const u32 sb = blockIdx.x;
+  const u32 pb = sb >> sbits;
+  const u32 subsel = sb & ((1u << sbits) - 1);
+  const u32 rem_bits = 32 - sbits;
+  const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const u32 n_waves = blockDim.x >> 6;
+  const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
+  for (u32 seg = wave; seg < P3_NWG; seg += n_waves) {
+    const u32 off = seg_off[pb * P3_NWG + seg];
+    const u32 n = ghist[pb * P3_NWG + seg];
+    for (u32 i = lane * 4; i < n; i += 256) {
+      const uint4 v = *reinterpret_cast<const uint4*>(&part[off + i]);
+      const u32 r4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        if (i + t < n && (r4[t] >> rem_bits) == subsel) {
+          const u32 rem = r4[t] & rem_mask;
+          u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
+          for (u32 probes = 0; probes < TS; probes++) {
+            u32 old = tkey[slot];
+            if (old == P3_EMPTY32) {
+              if (s_ndist >= limit) {
+                s_ovf = 1;
+                break;
+              }
+              old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
+              if (old == P3_EMPTY32) atomicAdd(&s_ndist, 1u);
+            }
+            if (old == P3_EMPTY32 || old == rem) {
+              atomicAdd(&tcnt[slot], 1u);
+              break;
+            }
+            slot = (slot + 1) & (TS - 1);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_ovf) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
+    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)s_ndist);
+    s_base_lo = (u32)base;
+    s_base_hi = (u32)(base >> 32);
+  }
+  __syncthreads();
+  const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
+  u32 my_solid = 0, my_max = 0;
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+    const u32 rem = tkey[i];
+    if (rem != P3_EMPTY32) {
+      const u32 c = tcnt[i];
+      const u32 idx = atomicAdd(&s_cur, 1u);
+      const u64 g = ((u64)pb << 32) | ((u64)subsel << rem_bits) | rem;
+      out_keys[base + idx] = unmix42(g);
+      out_counts[base + idx] = c;
+      my_solid += (c >= 2);
+      my_max = c > my_max ? c : my_max;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    my_solid += __shfl_down(my_solid, off, 64);
+    u32 o = __shfl_down(my_max, off, 64);
+    my_max = o > my_max ? o : my_max;
+  }
+  if (lane == 0) {
+    if (my_solid) atomicAdd(&s_nsolid, my_solid);
+    if (my_max) atomicMax(&s_max, my_max);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sb_info[sb] = make_uint4((u32)base, s_ndist, s_nsolid, (u32)(base >> 32));
+    if (s_nsolid) {
+      atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)s_nsolid);
+      atomicMax((unsigned long long*)&gstats[4], (unsigned long long)s_nsolid);
+    }
+    if (s_max) atomicMax((unsigned long long*)&gstats[2], (unsigned long long)s_max);
+  }
+#undef s_ndist
+#undef s_cur
+#undef s_base_lo
+#undef s_base_hi
+#undef s_nsolid
+#undef s_max
+#undef s_ovf
+}
+
+// ---- k_solid_regions: region[sb] = open-addressing table (rs slots) of the solid remainders of sub-bucket sb
+__global__ void __launch_bounds__(256) k_solid_regions(const u64* __restrict__ keys, const u32* __restrict__ counts,
+                                                       const uint4* __restrict__ sb_info, u32 sbits, u32 rs_log2,
+                                                       u32* __restrict__ solid) {
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 RS = 1u << rs_log2;
+  for (u32 i = threadIdx.x; i < RS; i += blockDim.x) lds[i] = P3_EMPTY32;
+  __syncthreads();
+  const u32 sb = blockIdx.x;
+  const uint4 info = sb_info[sb];
+  const u64 base = ((u64)info.w << 32) | info.x;
+  const u32 rem_mask = (1u << (32 - sbits)) - 1;
+  for (u32 i = threadIdx.x; i < info.y; i += blockDim.x) {
+    if (counts[base + i] >= P3_COV_THRESHOLD) {
+      const u32 rem = (u32)mix42(keys[base + i]) & rem_mask;
+      u32 slot = (rem * 0x9E3779B1u) >> (32 - rs_log2);
+      while (true) {
+        const u32 old = atomicCAS(&lds[slot], P3_EMPTY32, rem);
+        if (old == P3_EMPTY32 || old == rem) break;
+        slot = (slot + 1) & (RS - 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < RS; i += blockDim.x) solid[(u64)sb * RS + i] = lds[i];
+}
+
+__device__ __forceinline__ bool solid_lookup(const u32* __restrict__ solid, u32 sbits, u32 rs_log2, u64 key) {
+  const u64 g = mix42(key);
+  const u32 sb = (u32)(g >> (32 - sbits));
+  const u32 rem = (u32)g & ((1u << (32 - sbits)) - 1);
+  const u32 RS = 1u << rs_log2;
+  const u32* region = solid + (u64)sb * RS;
+  u32 slot = (rem * 0x9E3779B1u) >> (32 - rs_log2);
+  while (true) {
+    const u32 cur = region[slot];
+    if (cur == rem) return true;
+    if (cur == P3_EMPTY32) return false;
+    slot = (slot + 1) & (RS - 1);
+  }
+}
+
+// ---- k_gate_regions ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gate_regions(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+                                                      const u32* __restrict__ endm, u64 n_words,
+                                                      const u32* __restrict__ solid, u32 sbits, u32 rs_log2,
+                                                      u32* __restrict__ S) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+    LaneWords L = load_lane_words(fw, rcw, endm, w);
+    KmerRoll<1> kr;
+    kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+    const u64 vmask = (1ULL << 20) - 1;
+    u32 bits = 0;
+    for (int j = 0; j < 32; j++) {
+      if ((L.Elo & vmask) == 0) {
+        u64 lo, hi;
+        kr.canonical(lo, hi);
+        if (solid_lookup(solid, sbits, rs_log2, lo)) bits |= 1u << j;
+      }
+      kr.roll();
+      shr128(L.Elo, L.Ehi);
+    }
+    S[w] = bits;
+  }
+}

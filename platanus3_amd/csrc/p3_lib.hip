@@ -14,6 +14,7 @@
 
 #include "platanus3_amd.h"
 #include "p3_kernels.h"
+#include "p3_kernels_part.h"
 
 namespace {
 
@@ -50,11 +51,17 @@ struct p3_ctx {
   DevBuf fw, rcw, endm, S, P;
   bool packed = false;
 
-  // count table (direct) + compact export form
+  // count table: direct form (global open addressing) or partitioned form (LDS-counted buckets)
   DevBuf tkeys, tcounts, ckeys, ccounts, dstats;
   u64 cap = 0;
   bool counted = false;
   p3_count_stats cstats{};
+  int count_mode_opt = 0;   // 0 auto, 1 force direct, 2 force partitioned (error if it cannot be used)
+  int count_mode = 0;       // what the last p3_count_short used: 1 direct, 2 partitioned
+  int ts_log2_opt = P3_TS_LOG2_MAX;
+  u32 sbits = 1, rs_log2 = 6;
+  DevBuf ghist, seg_off, bucket_count, part, sb_info, solid;
+  bool ccounts_u32 = false;
 
   // bloom
   DevBuf bloom, seeds, seed_valid;
@@ -200,7 +207,7 @@ int do_pack(p3_ctx* c) {
   return P3_OK;
 }
 
-int do_count(p3_ctx* c) {
+int do_count_direct(p3_ctx* c) {
   int rc;
   // direct table: capacity = pow2 >= 1.5 * (upper bound on distinct keys = number of bases)
   u64 want = c->n_bases + c->n_bases / 2 + 1024;
@@ -209,7 +216,6 @@ int do_count(p3_ctx* c) {
   c->cap = cap;
   if ((rc = ensure(c, c->tkeys, cap * 8))) return rc;
   if ((rc = ensure(c, c->tcounts, cap * 8))) return rc;
-  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
   HIPCHK(c, hipMemsetAsync(c->tkeys.p, 0xff, cap * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(c->tcounts.p, 0, cap * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
@@ -229,8 +235,142 @@ int do_count(p3_ctx* c) {
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[2];
   c->cstats.n_windows = h[3];
+  c->count_mode = 1;
+  c->ccounts_u32 = false;
   c->counted = true;
   return P3_OK;
+}
+
+// limits of the partitioned form: 32-bit record indices
+bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG * P3_NB < (1ull << 31); }
+
+// Partitioned count.  Returns P3_OK with *overflowed = true when an LDS table overflowed even at the
+// largest sub-bucket split (caller then falls back to the direct form).
+int do_count_part(p3_ctx* c, bool* overflowed) {
+  int rc;
+  *overflowed = false;
+  const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+  if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
+  if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
+  if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
+  if ((rc = ensure(c, c->part, max_records * 4))) return rc;
+  u64 maxd = c->n_bases + 1;
+  if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
+  LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
+  LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
+         (u32*)c->bucket_count.p, st + 5);  // totals at st[5..7]
+  {
+    const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(c, hipFuncSetAttribute((const void*)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;
+    if (c->profiling) {
+      HIPCHK(c, hipEventCreate(&e0_));
+      HIPCHK(c, hipEventCreate(&e1_));
+      HIPCHK(c, hipEventRecord(e0_, c->stream));
+    }
+    hipLaunchKernelGGL(k_part_scatter, dim3(P3_NWG), dim3(P3_PART_THREADS), lds, c->stream, (const u64*)c->fw.p,
+                       (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p,
+                       (u32*)c->part.p);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+      HIPCHK(c, hipEventRecord(e1_, c->stream));
+      KStat* s_ = stat_for(c, "k_part_scatter");
+      s_->launches++;
+      s_->pending.push_back({e0_, e1_});
+    }
+  }
+  // sub-bucket split: aim at <= 64 Ki instances per LDS table; grow it if a table overflows
+  u32 sbits = 1;
+  while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > 65536) sbits++;
+  const u32 ts_log2 = (u32)c->ts_log2_opt;
+  u64 h[8];
+  for (;; sbits++) {
+    if (sbits > 5) {
+      *overflowed = true;
+      return P3_OK;
+    }
+    const u32 nsb = P3_NB << sbits;
+    if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
+    HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_part_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;
+    if (c->profiling) {
+      HIPCHK(c, hipEventCreate(&e0_));
+      HIPCHK(c, hipEventCreate(&e1_));
+      HIPCHK(c, hipEventRecord(e0_, c->stream));
+    }
+    hipLaunchKernelGGL(k_part_count, dim3(nsb), dim3(1024), lds, c->stream, (const u32*)c->part.p,
+                       (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->ckeys.p,
+                       (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+      HIPCHK(c, hipEventRecord(e1_, c->stream));
+      KStat* s_ = stat_for(c, "k_part_count");
+      s_->launches++;
+      s_->pending.push_back({e0_, e1_});
+    }
+    HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h[3] == 0) break;  // no LDS table overflowed
+  }
+  c->sbits = sbits;
+  c->cstats.n_distinct = h[0];
+  c->cstats.n_solid = h[1];
+  c->cstats.max_count = h[2];
+  c->cstats.n_windows = h[5];
+  // solid regions: slots = pow2 >= 1.6 * (largest number of solid keys in one sub-bucket), >= 64
+  u64 want = h[4] + (h[4] * 3) / 5 + 1;
+  u32 rs_log2 = 6;
+  while ((1ull << rs_log2) < want) rs_log2++;
+  c->rs_log2 = rs_log2;
+  const u32 nsb = P3_NB << sbits;
+  if ((rc = ensure(c, c->solid, ((size_t)nsb << rs_log2) * 4))) return rc;
+  {
+    const size_t lds = ((size_t)1 << rs_log2) * 4;
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_solid_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;
+    if (c->profiling) {
+      HIPCHK(c, hipEventCreate(&e0_));
+      HIPCHK(c, hipEventCreate(&e1_));
+      HIPCHK(c, hipEventRecord(e0_, c->stream));
+    }
+    hipLaunchKernelGGL(k_solid_regions, dim3(nsb), dim3(256), lds, c->stream, (const u64*)c->ckeys.p,
+                       (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, sbits, rs_log2, (u32*)c->solid.p);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {
+      HIPCHK(c, hipEventRecord(e1_, c->stream));
+      KStat* s_ = stat_for(c, "k_solid_regions");
+      s_->launches++;
+      s_->pending.push_back({e0_, e1_});
+    }
+  }
+  c->count_mode = 2;
+  c->ccounts_u32 = true;
+  c->counted = true;
+  return P3_OK;
+}
+
+int do_count(p3_ctx* c) {
+  int rc;
+  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
+  const bool can_part = part_applicable(c);
+  if (c->count_mode_opt == 2 && !can_part) return fail(c, P3_EBADARG, "partitioned count forced but input too large");
+  if (c->count_mode_opt != 1 && can_part) {
+    bool ovf = false;
+    if ((rc = do_count_part(c, &ovf))) return rc;
+    if (!ovf) return P3_OK;
+    if (c->count_mode_opt == 2) return fail(c, P3_ECAPACITY, "partitioned count forced but an LDS table overflowed");
+  }
+  return do_count_direct(c);
 }
 
 template <int NW>
@@ -249,8 +389,14 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  LAUNCH(c, "k_gate_direct", k_gate_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-         (const u32*)c->endm.p, c->n_words, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p, c->cap - 1, (u32*)c->S.p);
+  if (c->count_mode == 2) {
+    LAUNCH(c, "k_gate_regions", k_gate_regions, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p, c->sbits, c->rs_log2, (u32*)c->S.p);
+  } else {
+    LAUNCH(c, "k_gate_direct", k_gate_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p, c->cap - 1,
+           (u32*)c->S.p);
+  }
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   const ModM mm = make_modm(m);
   LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
@@ -324,7 +470,8 @@ int p3_destroy(p3_ctx* c) {
       (void)hipEventDestroy(pr.second);
     }
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
-                    &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid};
+                    &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
+                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -338,6 +485,31 @@ const char* p3_last_error(const p3_ctx* c) { return c ? c->err.c_str() : "null c
 int p3_set_profiling(p3_ctx* c, int on) {
   if (!c) return P3_EBADARG;
   c->profiling = on != 0;
+  return P3_OK;
+}
+
+int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return P3_EBADARG;
+  const std::string n(name);
+  if (n == "count_mode") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "count_mode must be 0 (auto), 1 (direct) or 2 (partitioned)");
+    c->count_mode_opt = (int)value;
+  } else if (n == "ts_log2") {
+    if (value < 4 || value > P3_TS_LOG2_MAX) return fail(c, P3_EBADARG, "ts_log2 must be in [4,%d]", P3_TS_LOG2_MAX);
+    c->ts_log2_opt = (int)value;
+  } else {
+    return fail(c, P3_EBADARG, "unknown option %s", name);
+  }
+  return P3_OK;
+}
+
+int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
+  if (!c || !name || !value) return P3_EBADARG;
+  const std::string n(name);
+  if (n == "count_mode") *value = c->count_mode;
+  else if (n == "sbits") *value = c->sbits;
+  else if (n == "rs_log2") *value = c->rs_log2;
+  else return fail(c, P3_EBADARG, "unknown info %s", name);
   return P3_OK;
 }
 
@@ -405,10 +577,17 @@ int p3_export_counts(p3_ctx* c, uint64_t* keys, uint64_t* counts, uint64_t cap, 
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<std::pair<u64, u64>> v(nd);
   {
-    std::vector<u64> hk(nd), hc(nd);
+    std::vector<u64> hk(nd);
     HIPCHK(c, hipMemcpy(hk.data(), c->ckeys.p, nd * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(hc.data(), c->ccounts.p, nd * 8, hipMemcpyDeviceToHost));
-    for (u64 i = 0; i < nd; i++) v[i] = {hk[i], hc[i]};
+    if (c->ccounts_u32) {
+      std::vector<u32> hc(nd);
+      HIPCHK(c, hipMemcpy(hc.data(), c->ccounts.p, nd * 4, hipMemcpyDeviceToHost));
+      for (u64 i = 0; i < nd; i++) v[i] = {hk[i], (u64)hc[i]};
+    } else {
+      std::vector<u64> hc(nd);
+      HIPCHK(c, hipMemcpy(hc.data(), c->ccounts.p, nd * 8, hipMemcpyDeviceToHost));
+      for (u64 i = 0; i < nd; i++) v[i] = {hk[i], hc[i]};
+    }
   }
   std::sort(v.begin(), v.end());
   for (u64 i = 0; i < nd; i++) {

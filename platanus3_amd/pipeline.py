@@ -11,7 +11,9 @@ from . import capi
 # kernel name -> stage whose ALGORITHMIC bytes it is credited with
 STAGE_OF = {
     "k_pack": "count", "k_endmask": "count", "k_count_direct": "count", "k_count_compact": "count",
-    "k_gate_direct": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
+    "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count",
+    "k_solid_regions": "count",
+    "k_gate_direct": "bloom", "k_gate_regions": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
 }
 
 

@@ -138,3 +138,21 @@ def test_idempotent_rerun(ctx, oracle):
     w2, s2, k2 = ctx.export_bloom(), ctx.export_seeds(), ctx.export_counts()
     assert np.array_equal(w1, w2) and np.array_equal(s1, s2)
     assert np.array_equal(k1[0], k2[0]) and np.array_equal(k1[1], k2[1])
+
+
+@pytest.mark.parametrize("mode,ts_log2,expect_mode", [(1, 14, 1), (2, 14, 2), (0, 8, 2), (0, 5, 1)])
+def test_count_paths(oracle, mode, ts_log2, expect_mode):
+    """direct global-table path, partitioned LDS path, partitioned with a re-split after LDS-table overflow
+    (ts_log2=8), and overflow at every split -> fallback to direct (ts_log2=5): identical results."""
+    c = capi.Context(0)
+    try:
+        c.set_option("count_mode", mode)
+        c.set_option("ts_log2", ts_log2)
+        b, o = synth.reads(seed=21, total_reads=30000, read_len=150)
+        m, H = oracle.estimate_bloom(int(b.size), 31)
+        run_and_compare(c, oracle, (b, o), 31, m, H)
+        assert c.get_info("count_mode") == expect_mode
+        if ts_log2 == 8:
+            assert c.get_info("sbits") > 1
+    finally:
+        c.close()
