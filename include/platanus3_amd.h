@@ -60,7 +60,11 @@ int p3_set_profiling(p3_ctx* ctx, int on);
  *                 global-table kernels, 2 = force the partitioned kernels (error if they cannot be used)
  *   "ts_log2"     log2 of the LDS count-table slots per sub-bucket (<= 14); small values force the
  *                 overflow -> re-split -> direct fallback chain in tests
- * p3_get_info reads back "count_mode" (path the last count used), "sbits", "rs_log2". */
+ *   "bloom_mode"  0 = auto (dedup form when the input fits), 1 = direct (H probes per passing window),
+ *                 2 = dedup (H probes per distinct passing k-mer; error if it cannot be used)
+ *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 13)
+ * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
+ * "rs_log2", "distinct_kmers". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 

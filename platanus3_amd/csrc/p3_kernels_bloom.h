@@ -1,0 +1,345 @@
+// p3_kernels_bloom.h -- the Bloom-build stage with duplicates removed on chip (gfx950, wave64).
+//
+// BF::add is idempotent (src/bloomfilter.cpp:68-74 only ever sets bits), and every distinct solid k-mer
+// is met ~coverage times in the reads (src/MakeBloomFilter.cpp:66-77), so the H probes are issued once
+// per DISTINCT passing canonical k-mer instead of once per window:
+//
+//   k_kmer_hist     windowed AND of solid bits (== RMQ >= 2, src/MakeBloomFilter.cpp:62,75) -> pass bitmap
+//                   P, and the per-(workgroup,bucket) histogram of passing canonical k-mers
+//   k_part_scan     (shared) exact 64-byte aligned segment offsets
+//   k_kmer_scatter  passing canonical k-mers staged per bucket in LDS, flushed as 64-byte chunks
+//   k_kmer_dedup    one workgroup per sub-bucket: LDS key set -> compact list of distinct keys
+//   k_bloom_insert  double hash + H probe positions + bit set per distinct key   (src/MyHash.cpp:21-35,
+//                   src/bloomfilter.cpp:58-74)
+#pragma once
+#include "p3_kernels_part.h"
+
+struct __attribute__((aligned(16))) Rec16 {
+  u64 lo, hi;
+};
+
+template <int NW>
+struct KRec;
+template <>
+struct KRec<1> {
+  typedef u64 type;
+};
+template <>
+struct KRec<2> {
+  typedef Rec16 type;
+};
+
+template <typename REC>
+struct Stg {
+  static constexpr u32 CHUNK = 64 / sizeof(REC);  // records per 64-byte chunk
+  static constexpr u32 CAP = 2 * CHUNK;           // one 128-byte LDS row per bucket
+};
+
+// bucket / slot hash of a k-mer key (ours, not part of the reference)
+template <int NW>
+__device__ __forceinline__ u64 khash(u64 lo, u64 hi) {
+  return NW == 1 ? mix64(lo ^ 0x9E3779B97F4A7C15ULL) : mix64(lo ^ mix64(hi ^ 0x9E3779B97F4A7C15ULL));
+}
+
+// ---- generic LDS stager: rows of 128 bytes (2 chunks), flushed by 4 lanes per bucket ----------------------
+template <typename REC>
+__device__ __forceinline__ void stage_flush(uint4* stage16, u32* cnt, u32* wpos, const u32* segb, REC* __restrict__ out,
+                                            bool final_flush) {
+  constexpr u32 CHUNK = Stg<REC>::CHUNK, CAP = Stg<REC>::CAP;
+  const u32 q = threadIdx.x & 3;
+  for (u32 it = 0; it < P3_NB / (P3_PART_THREADS / 4); it++) {
+    const u32 b = it * (P3_PART_THREADS / 4) + (threadIdx.x >> 2);
+    u32 n = cnt[b];
+    n = n < CAP ? n : CAP;
+    u32 nfl = (n / CHUNK) * CHUNK;
+    if (final_flush && (n % CHUNK)) nfl += CHUNK;
+    if (nfl) {
+      uint4* dst = reinterpret_cast<uint4*>(out + segb[b] + wpos[b]);
+      dst[q] = stage16[b * 8 + q];
+      if (nfl == 2 * CHUNK) dst[4 + q] = stage16[b * 8 + 4 + q];
+    }
+    if (!final_flush) {
+      const u32 r = n - nfl;  // < CHUNK records stay and move to the row start (source is in a later chunk)
+      if (nfl) {
+        REC* row = reinterpret_cast<REC*>(stage16 + b * 8);
+        REC tmp[(CHUNK + 3) / 4];
+#pragma unroll
+        for (u32 t = 0; t < (CHUNK + 3) / 4; t++)
+          if (q + 4 * t < r) tmp[t] = row[nfl + q + 4 * t];
+#pragma unroll
+        for (u32 t = 0; t < (CHUNK + 3) / 4; t++)
+          if (q + 4 * t < r) row[q + 4 * t] = tmp[t];
+      }
+      if (q == 0) {
+        cnt[b] = r;
+        wpos[b] += nfl;
+      }
+    }
+  }
+}
+
+// pass bits of the 32 window starts of word w (also returns how many k-windows are valid)
+struct PassWords {
+  u64 Slo, Shi;
+};
+
+// ---- k_kmer_hist ---------------------------------------------------------------------------------------------
+// stats[0] += valid k windows, stats[1] += passing windows
+template <int NW>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+                                                               const u32* __restrict__ endm, const u32* __restrict__ S,
+                                                               u64 n_words, u32 k, u32* __restrict__ ghist,
+                                                               u32* __restrict__ P, u64* __restrict__ stats) {
+  __shared__ u32 hist[P3_NB];
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  u64 begin, end;
+  part_word_range(n_words, blockIdx.x, begin, end);
+  const u64 vmask = (1ULL << (k - 1)) - 1;  // k-1 <= 63
+  const u64 smask = (1ULL << (k - 20)) - 1;
+  u64 n_valid = 0, n_pass = 0;
+  for (u64 w = begin + threadIdx.x; w < end; w += blockDim.x) {
+    LaneWords L = load_lane_words(fw, rcw, endm, w);
+    u64 Slo = (u64)S[w] | ((u64)S[w + 1] << 32);
+    u64 Shi = (u64)S[w + 2] | ((u64)S[w + 3] << 32);
+    KmerRoll<NW> kr;
+    kr.init(k, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+    u32 pbits = 0;
+    for (int j = 0; j < 32; j++) {
+      const bool valid = (L.Elo & vmask) == 0;
+      const bool pass = valid && ((~Slo & smask) == 0);
+      n_valid += valid;
+      if (pass) {
+        n_pass++;
+        pbits |= 1u << j;
+        u64 lo, hi;
+        kr.canonical(lo, hi);
+        atomicAdd(&hist[(u32)(khash<NW>(lo, hi) >> (64 - P3_PBITS))], 1u);
+      }
+      kr.roll();
+      shr128(L.Elo, L.Ehi);
+      shr128(Slo, Shi);
+    }
+    P[w] = pbits;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
+  for (int off = 32; off > 0; off >>= 1) {
+    n_valid += __shfl_down(n_valid, off, 64);
+    n_pass += __shfl_down(n_pass, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (n_valid) atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_valid);
+    if (n_pass) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_pass);
+  }
+}
+
+// ---- k_kmer_scatter -----------------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+                                                                  const u32* __restrict__ endm, const u32* __restrict__ P,
+                                                                  u64 n_words, u32 k, const u32* __restrict__ seg_off,
+                                                                  typename KRec<NW>::type* __restrict__ part) {
+  typedef typename KRec<NW>::type REC;
+  constexpr u32 CAP = Stg<REC>::CAP;
+  constexpr int RW = (NW == 1) ? 4 : 2;  // windows per lane per round: inflow/bucket stays well below CAP
+  extern __shared__ __align__(16) u32 lds[];
+  uint4* stage16 = reinterpret_cast<uint4*>(lds);  // NB rows x 128 B
+  u32* cnt = lds + P3_NB * 32;
+  u32* wpos = cnt + P3_NB;
+  u32* segb = wpos + P3_NB;
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+    cnt[i] = 0;
+    wpos[i] = 0;
+    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+  }
+  __syncthreads();
+  u64 begin, end;
+  part_word_range(n_words, blockIdx.x, begin, end);
+  for (u64 base = begin; base < end; base += blockDim.x) {
+    const u64 w = base + threadIdx.x;
+    const bool active = w < end;
+    KmerRoll<NW> kr;
+    u32 pbits = 0;
+    if (active) {
+      pbits = P[w];
+      kr.init(k, fw[w], fw[w + 1], fw[w + 2], rcw[w], rcw[w + 1], rcw[w + 2]);
+    }
+    // a whole block with no passing window skips the rounds (uniform decision)
+    if (!__syncthreads_or(pbits != 0)) continue;
+    for (int round = 0; round < 32 / RW; round++) {
+      REC rec[RW];
+      u32 bkt[RW];
+      u32 pend = 0;
+#pragma unroll
+      for (int i = 0; i < RW; i++) {
+        bkt[i] = 0;
+        if (pbits & 1u) {
+          u64 lo, hi;
+          kr.canonical(lo, hi);
+          if constexpr (NW == 1) rec[i] = lo;
+          else {
+            rec[i].lo = lo;
+            rec[i].hi = hi;
+          }
+          bkt[i] = (u32)(khash<NW>(lo, hi) >> (64 - P3_PBITS));
+          pend |= 1u << i;
+        }
+        pbits >>= 1;
+        if (active) kr.roll();
+      }
+      int more;
+      do {
+#pragma unroll
+        for (int i = 0; i < RW; i++) {
+          if (pend & (1u << i)) {
+            const u32 pos = atomicAdd(&cnt[bkt[i]], 1u);
+            if (pos < CAP) {
+              reinterpret_cast<REC*>(stage16 + bkt[i] * 8)[pos] = rec[i];
+              pend &= ~(1u << i);
+            }
+          }
+        }
+        __syncthreads();
+        stage_flush<REC>(stage16, cnt, wpos, segb, part, false);
+        more = __syncthreads_or(pend != 0);
+      } while (more);
+    }
+  }
+  stage_flush<REC>(stage16, cnt, wpos, segb, part, true);
+}
+
+// ---- k_kmer_dedup ---------------------------------------------------------------------------------------------
+// gstats[0] = distinct cursor, gstats[3] = overflow flag.  LDS: NW==1: u64 slots; NW==2: state + lo + hi.
+template <int NW>
+__global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::type* __restrict__ part,
+                                                     const u32* __restrict__ seg_off, const u32* __restrict__ ghist,
+                                                     u32 sbits, u32 ts_log2, u64* __restrict__ out_keys,
+                                                     u64* __restrict__ gstats) {
+  typedef typename KRec<NW>::type REC;
+  constexpr u32 CHUNK = Stg<REC>::CHUNK;
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 TS = 1u << ts_log2;
+  u64* tlo = reinterpret_cast<u64*>(lds);
+  u64* thi = tlo + (NW == 2 ? TS : 0);
+  u32* tstate = reinterpret_cast<u32*>(thi + TS);  // NW==2 only
+  u32* sc = (NW == 2) ? (tstate + TS) : reinterpret_cast<u32*>(tlo + TS);
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+    tlo[i] = ~0ULL;
+    if (NW == 2) {
+      thi[i] = ~0ULL;
+      tstate[i] = 0;
+    }
+  }
+  if (threadIdx.x < 8) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 sb = blockIdx.x;
+  const u32 pb = sb >> sbits;
+  const u32 subsel = sb & ((1u << sbits) - 1);
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+  const u32 limit = TS - (TS >> 3);
+  (void)CHUNK;
+  for (u32 seg = wave; seg < P3_NWG; seg += n_waves) {
+    const u32 off = seg_off[pb * P3_NWG + seg];
+    const u32 n = ghist[pb * P3_NWG + seg];
+    for (u32 i = lane; i < n; i += 64) {
+      u64 lo, hi = 0;
+      if constexpr (NW == 1) lo = part[off + i];
+      else {
+        const Rec16 r = part[off + i];
+        lo = r.lo;
+        hi = r.hi;
+      }
+      const u64 h = khash<NW>(lo, hi);
+      if (sbits && ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) != subsel) continue;
+      u32 slot = (u32)(h >> 16) & (TS - 1);
+      bool placed = false;
+      for (u32 probes = 0; probes < TS; probes++) {
+        if constexpr (NW == 1) {
+          u64 old = tlo[slot];
+          if (old == ~0ULL) {
+            if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
+              sc[6] = 1;
+              break;
+            }
+            old = atomicCAS((unsigned long long*)&tlo[slot], ~0ULL, (unsigned long long)lo);
+            if (old == ~0ULL) {
+              atomicAdd(&sc[0], 1u);
+              placed = true;
+              break;
+            }
+          }
+          if (old == lo) {
+            placed = true;
+            break;
+          }
+        } else {
+          // claim protocol: 0 = empty, 1 = being written, 2 = full (no 128-bit LDS compare-and-swap)
+          u32 st = __hip_atomic_load(&tstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (st == 0) {
+            if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
+              sc[6] = 1;
+              break;
+            }
+            if (atomicCAS(&tstate[slot], 0u, 1u) == 0u) {
+              tlo[slot] = lo;
+              thi[slot] = hi;
+              __threadfence_block();
+              __hip_atomic_store(&tstate[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              atomicAdd(&sc[0], 1u);
+              placed = true;
+              break;
+            }
+            probes--;  // lost the race: look at the same slot again
+            continue;
+          }
+          if (st == 1) {
+            probes--;  // writer in flight (it never waits on us): re-read
+            continue;
+          }
+          __threadfence_block();
+          if (tlo[slot] == lo && thi[slot] == hi) {
+            placed = true;
+            break;
+          }
+        }
+        slot = (slot + 1) & (TS - 1);
+      }
+      if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sc[6]) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
+    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)sc[0]);
+    sc[2] = (u32)base;
+    sc[3] = (u32)(base >> 32);
+  }
+  __syncthreads();
+  const u64 base = ((u64)sc[3] << 32) | sc[2];
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+    const bool full = (NW == 1) ? (tlo[i] != ~0ULL) : (tstate[i] == 2u);
+    if (full) {
+      const u32 idx = atomicAdd(&sc[1], 1u);
+      out_keys[(base + idx) * NW] = tlo[i];
+      if (NW == 2) out_keys[(base + idx) * NW + 1] = thi[i];
+    }
+  }
+}
+
+// ---- k_bloom_insert: H probes per distinct key, global atomicOr -------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
+                                                      u32* __restrict__ bloom) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
+    u64 h1, h2;
+    double_hash_key<NW>(lo, hi, k, h1, h2);
+    Probe pr = probe_begin(h1, h2, mm);
+    for (u32 nn = 0; nn < H; nn++) {
+      atomicOr(&bloom[pr.r >> 5], 1u << (pr.r & 31));
+      probe_step(pr, mm);
+    }
+  }
+}

@@ -285,22 +285,22 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
         if (i + t < n && (r4[t] >> rem_bits) == subsel) {
           const u32 rem = r4[t] & rem_mask;
           u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
+          bool placed = false;
           for (u32 probes = 0; probes < TS; probes++) {
             u32 old = tkey[slot];
             if (old == P3_EMPTY32) {
-              if (s_ndist >= limit) {
-                s_ovf = 1;
-                break;
-              }
+              if (__hip_atomic_load(&s_ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) break;
               old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
               if (old == P3_EMPTY32) atomicAdd(&s_ndist, 1u);
             }
             if (old == P3_EMPTY32 || old == rem) {
               atomicAdd(&tcnt[slot], 1u);
+              placed = true;
               break;
             }
             slot = (slot + 1) & (TS - 1);
           }
+          if (!placed) s_ovf = 1;  // table (nearly) full: the host re-splits or falls back
         }
       }
     }

@@ -15,6 +15,7 @@
 #include "platanus3_amd.h"
 #include "p3_kernels.h"
 #include "p3_kernels_part.h"
+#include "p3_kernels_bloom.h"
 
 namespace {
 
@@ -62,6 +63,12 @@ struct p3_ctx {
   u32 sbits = 1, rs_log2 = 6;
   DevBuf ghist, seg_off, bucket_count, part, sb_info, solid;
   bool ccounts_u32 = false;
+  int bloom_mode_opt = 0;   // 0 auto, 1 direct (one insert per window), 2 dedup (one insert per distinct k-mer)
+  int bloom_mode = 0;
+  int tsk_log2_opt = 13;    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
+  u32 ksbits = 0;
+  DevBuf kpart, dkeys;
+  u64 n_distinct_k = 0;
 
   // bloom
   DevBuf bloom, seeds, seed_valid;
@@ -156,6 +163,26 @@ int drain_stats(p3_ctx* c) {
       s_->launches++;                                                                      \
       s_->pending.push_back({e0_, e1_});                                                   \
     }                                                                                      \
+  } while (0)
+
+#define LAUNCH_LDS(c, name, kernel, grid, block, ldsbytes, ...)                                  \
+  do {                                                                                           \
+    HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(ldsbytes)));                                             \
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                     \
+    if ((c)->profiling) {                                                                        \
+      HIPCHK(c, hipEventCreate(&e0_));                                                           \
+      HIPCHK(c, hipEventCreate(&e1_));                                                           \
+      HIPCHK(c, hipEventRecord(e0_, (c)->stream));                                               \
+    }                                                                                            \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (ldsbytes), (c)->stream, __VA_ARGS__);   \
+    HIPCHK(c, hipGetLastError());                                                                \
+    if ((c)->profiling) {                                                                        \
+      HIPCHK(c, hipEventRecord(e1_, (c)->stream));                                               \
+      KStat* s_ = stat_for(c, name);                                                             \
+      s_->launches++;                                                                            \
+      s_->pending.push_back({e0_, e1_});                                                         \
+    }                                                                                            \
   } while (0)
 
 inline unsigned grid_for(u64 items, unsigned block = 256, unsigned max_blocks = 256 * 16) {
@@ -373,8 +400,11 @@ int do_count(p3_ctx* c) {
   return do_count_direct(c);
 }
 
+// Bloom stage.  Gate (S bits) first, then either the direct form (H probes per passing window) or the
+// dedup form (partition passing canonical k-mers, LDS set per sub-bucket, H probes per distinct key).
 template <int NW>
 int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
+  typedef typename KRec<NW>::type REC;
   int rc;
   const u64 nwa = c->n_words + P3_PAD_WORDS;
   const u64 bwords = (m + 63) / 64;
@@ -399,19 +429,69 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   }
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   const ModM mm = make_modm(m);
-  LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
-         (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p,
-         (u32*)c->P.p, st + 8);
+  bool use_dedup = c->bloom_mode_opt != 1 && part_applicable(c);
+  if (c->bloom_mode_opt == 2 && !use_dedup) return fail(c, P3_EBADARG, "dedup Bloom build forced but input too large");
+  u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (use_dedup) {
+    const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+    if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
+    if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
+    if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
+    if ((rc = ensure(c, c->kpart, max_records * sizeof(REC)))) return rc;
+    if ((rc = ensure(c, c->dkeys, (c->n_words * 32 + 1) * 8 * NW))) return rc;
+    LAUNCH(c, "k_kmer_hist", (k_kmer_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, (u32*)c->ghist.p, (u32*)c->P.p, st + 8);
+    LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
+           (u32*)c->bucket_count.p, st + 12);  // totals at st[12..14]
+    const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+    LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
+               (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->P.p, c->n_words, k,
+               (const u32*)c->seg_off.p, (REC*)c->kpart.p);
+    u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 1 : 0);
+    u32 sbits = 0;
+    while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
+    for (;; sbits++) {
+      if (sbits > 5) {
+        use_dedup = false;  // every split overflowed: fall back to the direct form below
+        break;
+      }
+      const u32 nsb = P3_NB << sbits;
+      HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64;
+      LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), nsb, 1024, lds, (const REC*)c->kpart.p,
+                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st);
+      HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (h[3] == 0) break;
+    }
+    if (use_dedup) {
+      c->ksbits = sbits;
+      c->n_distinct_k = h[0];
+      LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), grid_for(h[0]), 256, (const u64*)c->dkeys.p, h[0], k, mm, H,
+             (u32*)c->bloom.p);
+      c->bloom_mode = 2;
+    } else if (c->bloom_mode_opt == 2) {
+      return fail(c, P3_ECAPACITY, "dedup Bloom build forced but an LDS set overflowed");
+    } else {
+      HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
+    }
+  }
+  if (!use_dedup) {
+    LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
+           (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p,
+           (u32*)c->P.p, st + 8);
+    c->bloom_mode = 1;
+  }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
   LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads), 256, c->d_offsets, c->n_reads, c->min_len, k,
          (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-  u64 h[3];
-  HIPCHK(c, hipMemcpyAsync(h, st + 8, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  u64 hb[3];
+  HIPCHK(c, hipMemcpyAsync(hb, st + 8, sizeof hb, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->bstats.n_windows_k = h[0];
-  c->bstats.n_passing = h[1];
-  c->bstats.n_seed_reads = h[2];
+  c->bstats.n_windows_k = hb[0];
+  c->bstats.n_passing = hb[1];
+  c->bstats.n_seed_reads = hb[2];
   c->k = k;
   c->m = m;
   c->H = H;
@@ -471,7 +551,7 @@ int p3_destroy(p3_ctx* c) {
     }
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
-                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid};
+                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -494,6 +574,12 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   if (n == "count_mode") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "count_mode must be 0 (auto), 1 (direct) or 2 (partitioned)");
     c->count_mode_opt = (int)value;
+  } else if (n == "bloom_mode") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "bloom_mode must be 0 (auto), 1 (direct) or 2 (dedup)");
+    c->bloom_mode_opt = (int)value;
+  } else if (n == "tsk_log2") {
+    if (value < 4 || value > 13) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,13]");
+    c->tsk_log2_opt = (int)value;
   } else if (n == "ts_log2") {
     if (value < 4 || value > P3_TS_LOG2_MAX) return fail(c, P3_EBADARG, "ts_log2 must be in [4,%d]", P3_TS_LOG2_MAX);
     c->ts_log2_opt = (int)value;
@@ -507,6 +593,9 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   if (!c || !name || !value) return P3_EBADARG;
   const std::string n(name);
   if (n == "count_mode") *value = c->count_mode;
+  else if (n == "bloom_mode") *value = c->bloom_mode;
+  else if (n == "ksbits") *value = c->ksbits;
+  else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
   else return fail(c, P3_EBADARG, "unknown info %s", name);

@@ -13,6 +13,7 @@ STAGE_OF = {
     "k_pack": "count", "k_endmask": "count", "k_count_direct": "count", "k_count_compact": "count",
     "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count",
     "k_solid_regions": "count",
+    "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_bloom_insert": "bloom",
     "k_gate_direct": "bloom", "k_gate_regions": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
 }
 
