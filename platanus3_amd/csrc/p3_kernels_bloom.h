@@ -231,83 +231,78 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
       tstate[i] = 0;
     }
   }
-  if (threadIdx.x < 8) sc[threadIdx.x] = 0;
+  if (threadIdx.x < 16) sc[threadIdx.x] = 0;
   __syncthreads();
   const u32 sb = blockIdx.x;
   const u32 pb = sb >> sbits;
   const u32 subsel = sb & ((1u << sbits) - 1);
-  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
   const u32 limit = TS - (TS >> 3);
   (void)CHUNK;
-  for (u32 seg = wave; seg < P3_NWG; seg += n_waves) {
-    const u32 off = seg_off[pb * P3_NWG + seg];
-    const u32 n = ghist[pb * P3_NWG + seg];
-    for (u32 i = lane; i < n; i += 64) {
-      u64 lo, hi = 0;
-      if constexpr (NW == 1) lo = part[off + i];
-      else {
-        const Rec16 r = part[off + i];
-        lo = r.lo;
-        hi = r.hi;
-      }
-      const u64 h = khash<NW>(lo, hi);
-      if (sbits && ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) != subsel) continue;
-      u32 slot = (u32)(h >> 16) & (TS - 1);
-      bool placed = false;
-      for (u32 probes = 0; probes < TS; probes++) {
-        if constexpr (NW == 1) {
-          u64 old = tlo[slot];
-          if (old == ~0ULL) {
-            if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
-              sc[6] = 1;
-              break;
-            }
-            old = atomicCAS((unsigned long long*)&tlo[slot], ~0ULL, (unsigned long long)lo);
-            if (old == ~0ULL) {
-              atomicAdd(&sc[0], 1u);
-              placed = true;
-              break;
-            }
-          }
-          if (old == lo) {
-            placed = true;
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC rec) {
+    u64 lo, hi = 0;
+    if constexpr (NW == 1) lo = rec;
+    else {
+      lo = rec.lo;
+      hi = rec.hi;
+    }
+    const u64 h = khash<NW>(lo, hi);
+    if (sbits && ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) != subsel) return;
+    u32 slot = (u32)(h >> 16) & (TS - 1);
+    bool placed = false;
+    for (u32 probes = 0; probes < TS; probes++) {
+      if constexpr (NW == 1) {
+        u64 old = tlo[slot];
+        if (old == ~0ULL) {
+          if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
+            sc[6] = 1;
             break;
           }
-        } else {
-          // claim protocol: 0 = empty, 1 = being written, 2 = full (no 128-bit LDS compare-and-swap)
-          u32 st = __hip_atomic_load(&tstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (st == 0) {
-            if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
-              sc[6] = 1;
-              break;
-            }
-            if (atomicCAS(&tstate[slot], 0u, 1u) == 0u) {
-              tlo[slot] = lo;
-              thi[slot] = hi;
-              __threadfence_block();
-              __hip_atomic_store(&tstate[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              atomicAdd(&sc[0], 1u);
-              placed = true;
-              break;
-            }
-            probes--;  // lost the race: look at the same slot again
-            continue;
-          }
-          if (st == 1) {
-            probes--;  // writer in flight (it never waits on us): re-read
-            continue;
-          }
-          __threadfence_block();
-          if (tlo[slot] == lo && thi[slot] == hi) {
+          old = atomicCAS((unsigned long long*)&tlo[slot], ~0ULL, (unsigned long long)lo);
+          if (old == ~0ULL) {
+            atomicAdd(&sc[0], 1u);
             placed = true;
             break;
           }
         }
-        slot = (slot + 1) & (TS - 1);
+        if (old == lo) {
+          placed = true;
+          break;
+        }
+      } else {
+        // claim protocol: 0 = empty, 1 = being written, 2 = full (no 128-bit LDS compare-and-swap)
+        u32 st = __hip_atomic_load(&tstate[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (st == 0) {
+          if (__hip_atomic_load(&sc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) {
+            sc[6] = 1;
+            break;
+          }
+          if (atomicCAS(&tstate[slot], 0u, 1u) == 0u) {
+            tlo[slot] = lo;
+            thi[slot] = hi;
+            __threadfence_block();
+            __hip_atomic_store(&tstate[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicAdd(&sc[0], 1u);
+            placed = true;
+            break;
+          }
+          probes--;  // lost the race: look at the same slot again
+          continue;
+        }
+        if (st == 1) {
+          probes--;  // writer in flight (it never waits on us): re-read
+          continue;
+        }
+        __threadfence_block();
+        if (tlo[slot] == lo && thi[slot] == hi) {
+          placed = true;
+          break;
+        }
       }
-      if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
+      slot = (slot + 1) & (TS - 1);
     }
-  }
+    if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
+  });
   __syncthreads();
   if (threadIdx.x == 0) {
     if (sc[6]) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
@@ -342,4 +337,125 @@ __global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ ke
       probe_step(pr, mm);
     }
   }
+}
+
+// ---- sliced Bloom build: probe positions partitioned by bit-vector slice, OR-ed in LDS ------------------------
+// The m-bit vector is cut into <= 1024 slices of 2^slice_log2 bits.  k_pos_hist / k_pos_scatter partition the
+// H probe positions of every distinct key by slice (same exact-offset, 64-byte-chunk machinery as the k-mer
+// partition); k_bloom_slices ORs one slice in LDS and stores it whole -- no global atomics at all.
+__device__ __forceinline__ void pos_key_range(u64 n, u32 wg, u64& begin, u64& end) {
+  const u64 per = (n + P3_NWG - 1) / P3_NWG;
+  begin = (u64)wg * per;
+  end = begin + per;
+  if (begin > n) begin = n;
+  if (end > n) end = n;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
+                                                              u32 slice_log2, u32* __restrict__ ghist) {
+  __shared__ u32 hist[P3_NB];
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  u64 begin, end;
+  pos_key_range(n, blockIdx.x, begin, end);
+  for (u64 i = begin + threadIdx.x; i < end; i += blockDim.x) {
+    const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
+    u64 h1, h2;
+    double_hash_key<NW>(lo, hi, k, h1, h2);
+    Probe pr = probe_begin(h1, h2, mm);
+    for (u32 nn = 0; nn < H; nn++) {
+      atomicAdd(&hist[(u32)(pr.r >> slice_log2)], 1u);
+      probe_step(pr, mm);
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
+}
+
+template <int NW>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, u64 n, u32 k, ModM mm,
+                                                                 u32 H, u32 slice_log2, const u32* __restrict__ seg_off,
+                                                                 u32* __restrict__ out) {
+  constexpr u32 CAP = Stg<u32>::CAP;
+  constexpr u32 PR = 8;  // probes per lane per round
+  extern __shared__ __align__(16) u32 lds[];
+  uint4* stage16 = reinterpret_cast<uint4*>(lds);
+  u32* stage = lds;
+  u32* cnt = lds + P3_NB * 32;
+  u32* wpos = cnt + P3_NB;
+  u32* segb = wpos + P3_NB;
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+    cnt[i] = 0;
+    wpos[i] = 0;
+    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+  }
+  __syncthreads();
+  u64 begin, end;
+  pos_key_range(n, blockIdx.x, begin, end);
+  const u32 smask = (1u << slice_log2) - 1;
+  for (u64 base = begin; base < end; base += blockDim.x) {
+    const u64 i = base + threadIdx.x;
+    const bool active = i < end;
+    Probe pr;
+    if (active) {
+      const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
+      u64 h1, h2;
+      double_hash_key<NW>(lo, hi, k, h1, h2);
+      pr = probe_begin(h1, h2, mm);
+    }
+    for (u32 done = 0; done < H; done += PR) {
+      u32 rec[PR], bkt[PR];
+      u32 pend = 0;
+#pragma unroll
+      for (u32 t = 0; t < PR; t++) {
+        rec[t] = 0;
+        bkt[t] = 0;
+        if (active && done + t < H) {
+          rec[t] = (u32)pr.r & smask;
+          bkt[t] = (u32)(pr.r >> slice_log2);
+          pend |= 1u << t;
+          probe_step(pr, mm);
+        }
+      }
+      int more;
+      do {
+#pragma unroll
+        for (u32 t = 0; t < PR; t++) {
+          if (pend & (1u << t)) {
+            const u32 pos = atomicAdd(&cnt[bkt[t]], 1u);
+            if (pos < CAP) {
+              stage[bkt[t] * CAP + pos] = rec[t];
+              pend &= ~(1u << t);
+            }
+          }
+        }
+        __syncthreads();
+        stage_flush<u32>(stage16, cnt, wpos, segb, out, false);
+        more = __syncthreads_or(pend != 0);
+      } while (more);
+    }
+  }
+  stage_flush<u32>(stage16, cnt, wpos, segb, out, true);
+}
+
+// one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else
+// writes it in this mode).  n_u32 = number of u32 words of the whole vector.
+__global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+                                                       const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
+                                                       u32* __restrict__ bloom) {
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 words = 1u << (slice_log2 - 5);
+  u32* bm = lds;
+  u32* sc = lds + words;
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  for (u32 i = threadIdx.x; i < words; i += blockDim.x) bm[i] = 0;
+  __syncthreads();
+  const u32 s = blockIdx.x;
+  bucket_for_each<u32>(part, seg_off, ghist, s, valid, sc + 8,
+                       [&](u32 r) { atomicOr(&bm[r >> 5], 1u << (r & 31)); });
+  __syncthreads();
+  const u64 w0 = (u64)s * words;
+  for (u32 i = threadIdx.x; i < words; i += blockDim.x)
+    if (w0 + i < n_u32) bloom[w0 + i] = bm[i];
 }

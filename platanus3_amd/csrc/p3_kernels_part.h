@@ -35,6 +35,8 @@ __host__ __device__ constexpr u64 p3_modinv64(u64 a) {
 }
 #define P3_MIX_CINV (p3_modinv64(P3_MIX_C) & P3_MASK42)
 
+#include "p3_bucket_reader.h"
+
 __host__ __device__ __forceinline__ u64 mix42(u64 x) {
   x ^= x >> 21;
   return (x * P3_MIX_C) & P3_MASK42;
@@ -271,40 +273,30 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   const u32 subsel = sb & ((1u << sbits) - 1);
   const u32 rem_bits = 32 - sbits;
   const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
-  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const u32 n_waves = blockDim.x >> 6;
+  const u32 lane = threadIdx.x & 63;
   const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
-  for (u32 seg = wave; seg < P3_NWG; seg += n_waves) {
-    const u32 off = seg_off[pb * P3_NWG + seg];
-    const u32 n = ghist[pb * P3_NWG + seg];
-    for (u32 i = lane * 4; i < n; i += 256) {
-      const uint4 v = *reinterpret_cast<const uint4*>(&part[off + i]);
-      const u32 r4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        if (i + t < n && (r4[t] >> rem_bits) == subsel) {
-          const u32 rem = r4[t] & rem_mask;
-          u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
-          bool placed = false;
-          for (u32 probes = 0; probes < TS; probes++) {
-            u32 old = tkey[slot];
-            if (old == P3_EMPTY32) {
-              if (__hip_atomic_load(&s_ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) break;
-              old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
-              if (old == P3_EMPTY32) atomicAdd(&s_ndist, 1u);
-            }
-            if (old == P3_EMPTY32 || old == rem) {
-              atomicAdd(&tcnt[slot], 1u);
-              placed = true;
-              break;
-            }
-            slot = (slot + 1) & (TS - 1);
-          }
-          if (!placed) s_ovf = 1;  // table (nearly) full: the host re-splits or falls back
-        }
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  bucket_for_each<u32>(part, seg_off, ghist, pb, valid, sc + 8, [&](u32 r) {
+    if ((r >> rem_bits) != subsel) return;
+    const u32 rem = r & rem_mask;
+    u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
+    bool placed = false;
+    for (u32 probes = 0; probes < TS; probes++) {
+      u32 old = tkey[slot];
+      if (old == P3_EMPTY32) {
+        if (__hip_atomic_load(&s_ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) break;
+        old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
+        if (old == P3_EMPTY32) atomicAdd(&s_ndist, 1u);
       }
+      if (old == P3_EMPTY32 || old == rem) {
+        atomicAdd(&tcnt[slot], 1u);
+        placed = true;
+        break;
+      }
+      slot = (slot + 1) & (TS - 1);
     }
-  }
+    if (!placed) s_ovf = 1;  // table (nearly) full: the host re-splits or falls back
+  });
   __syncthreads();
   if (threadIdx.x == 0) {
     if (s_ovf) atomicAdd((unsigned long long*)&gstats[3], 1ULL);

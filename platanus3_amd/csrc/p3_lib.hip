@@ -67,7 +67,8 @@ struct p3_ctx {
   int bloom_mode = 0;
   int tsk_log2_opt = 13;    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0;
-  DevBuf kpart, dkeys;
+  DevBuf kpart, dkeys, ppart;
+  int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
 
   // bloom
@@ -327,7 +328,7 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
     const u32 nsb = P3_NB << sbits;
     if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
     HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64;
+    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP;
     HIPCHK(c, hipFuncSetAttribute((const void*)k_part_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0_ = nullptr, e1_ = nullptr;
     if (c->profiling) {
@@ -457,7 +458,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       }
       const u32 nsb = P3_NB << sbits;
       HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64;
+      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VALID_CAP;
       LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), nsb, 1024, lds, (const REC*)c->kpart.p,
                  (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st);
       HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -467,9 +468,29 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (use_dedup) {
       c->ksbits = sbits;
       c->n_distinct_k = h[0];
-      LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), grid_for(h[0]), 256, (const u64*)c->dkeys.p, h[0], k, mm, H,
-             (u32*)c->bloom.p);
-      c->bloom_mode = 2;
+      // slices of 2^slice_log2 bits, at most 1024 of them and at most 128 KiB of LDS each
+      u32 slice_log2 = 10;
+      while (((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
+      const u64 n_pos = h[0] * (u64)H;
+      const bool sliced = c->bloom_slices_opt && slice_log2 <= 20 && n_pos + 16ull * P3_NWG * P3_NB < (1ull << 31);
+      if (sliced) {
+        const u32 ns = (u32)((m + ((1ull << slice_log2) - 1)) >> slice_log2);
+        if ((rc = ensure(c, c->ppart, (n_pos + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+        LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, h[0], k, mm, H,
+               slice_log2, (u32*)c->ghist.p);
+        LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
+               (u32*)c->bucket_count.p, st + 12);
+        LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                   h[0], k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p);
+        const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
+        LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p);
+        c->bloom_mode = 3;
+      } else {
+        LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), grid_for(h[0]), 256, (const u64*)c->dkeys.p, h[0], k, mm, H,
+               (u32*)c->bloom.p);
+        c->bloom_mode = 2;
+      }
     } else if (c->bloom_mode_opt == 2) {
       return fail(c, P3_ECAPACITY, "dedup Bloom build forced but an LDS set overflowed");
     } else {
@@ -551,7 +572,7 @@ int p3_destroy(p3_ctx* c) {
     }
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
-                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys};
+                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -577,6 +598,8 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "bloom_mode") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "bloom_mode must be 0 (auto), 1 (direct) or 2 (dedup)");
     c->bloom_mode_opt = (int)value;
+  } else if (n == "bloom_slices") {
+    c->bloom_slices_opt = value != 0;
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 13) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,13]");
     c->tsk_log2_opt = (int)value;

@@ -158,13 +158,17 @@ def test_count_paths(oracle, mode, ts_log2, expect_mode):
         c.close()
 
 
-@pytest.mark.parametrize("k,mode,tsk,expect_mode", [(31, 1, 13, 1), (31, 2, 13, 2), (31, 0, 7, 2), (31, 0, 4, 1),
-                                                    (63, 2, 13, 2), (63, 0, 7, 2), (41, 1, 13, 1)])
+@pytest.mark.parametrize("k,mode,tsk,expect_mode", [(31, 1, 13, 1), (31, 2, 13, 3), (31, 0, 7, 3), (31, 0, 4, 1),
+                                                    (63, 2, 13, 3), (63, 0, 7, 3), (41, 1, 13, 1), (31, -2, 13, 2),
+                                                    (63, -2, 13, 2)])
 def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
     """direct (probe per window) vs dedup (probe per distinct k-mer) Bloom build, including LDS-set overflow
     -> re-split (tsk_log2=7) and overflow at every split -> direct fallback (tsk_log2=4)."""
     c = capi.Context(0)
     try:
+        if mode < 0:  # dedup, but global atomicOr per probe instead of LDS slices
+            c.set_option("bloom_slices", 0)
+            mode = -mode
         c.set_option("bloom_mode", mode)
         c.set_option("tsk_log2", tsk)
         b, o = synth.reads(seed=23, total_reads=60000, read_len=150)
