@@ -9,9 +9,10 @@
 #pragma once
 // (included by p3_kernels_part.h after the partition constants are defined)
 
-#define P3_VALID_CAP 24576u  // chunks per window (bytes of LDS) = 393,216 records
+#define P3_VALID_CAP 8192u  // chunks per window (bytes of LDS) = 131,072 records
 
-// Calls f(rec) for every real record of bucket pb.  ALL threads of the workgroup must call this (it
+// Calls f(recs, active_mask) with batches of 4*(16/sizeof(REC)) records of bucket pb (bit i of the mask says
+// whether recs[i] is a real record).  ALL threads of the workgroup must call this (it
 // synchronises).  valid: LDS byte array of P3_VALID_CAP entries; sc2: two LDS u32 scratch words.
 template <typename REC, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
@@ -46,40 +47,42 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
     __syncthreads();
     const uint4* vec = reinterpret_cast<const uint4*>(part + start) + (u64)wb * VPC;
     const u32 nvec = wn * VPC;
-    // four 16-byte loads in flight per lane before any record is consumed (the consumers are LDS-latency
-    // chains; without this a wave has a single outstanding HBM request)
-    auto consume = [&](const uint4& v, u32 j) {
-      const u32 nvalid = valid[j / VPC];
-      const u32 first = (j % VPC) * RPV;  // index of this vector's first record inside its chunk
-      if constexpr (sizeof(REC) == 4) {
-        const u32 r4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (u32 t = 0; t < 4; t++)
-          if (first + t < nvalid) f(r4[t]);
-      } else if constexpr (sizeof(REC) == 8) {
-        const u64 r2[2] = {((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z};
-#pragma unroll
-        for (u32 t = 0; t < 2; t++)
-          if (first + t < nvalid) f(r2[t]);
-      } else {
-        REC r;
-        r.lo = ((u64)v.y << 32) | v.x;
-        r.hi = ((u64)v.w << 32) | v.z;
-        if (first < nvalid) f(r);
-      }
-    };
+    // Four 16-byte loads in flight per lane; the 4*RPV records they hold are handed to f as ONE batch so
+    // that the consumer can issue its LDS lookups for all of them before using any (LDS latency chains,
+    // not HBM, bound these kernels at 4 waves per SIMD).
     const u32 B = blockDim.x;
-    u32 j = threadIdx.x;
-    for (; j + 3 * B < nvec; j += 4 * B) {
-      const uint4 v0 = vec[j], v1 = vec[j + B], v2 = vec[j + 2 * B], v3 = vec[j + 3 * B];
-      consume(v0, j);
-      consume(v1, j + B);
-      consume(v2, j + 2 * B);
-      consume(v3, j + 3 * B);
-    }
-    for (; j < nvec; j += B) {
-      const uint4 v = vec[j];
-      consume(v, j);
+    for (u32 jb = 0; jb < nvec; jb += 4 * B) {  // uniform trip count: consumers use wave-wide ballots
+      const u32 j0 = jb + threadIdx.x;
+      uint4 v[4];
+      u32 jj[4];
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        jj[u] = j0 + u * B;
+        v[u] = (jj[u] < nvec) ? vec[jj[u]] : make_uint4(0, 0, 0, 0);
+      }
+      REC recs[4 * RPV];
+      u32 act = 0;
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        const u32 nvalid = (jj[u] < nvec) ? (u32)valid[jj[u] / VPC] : 0u;
+        const u32 first = (jj[u] % VPC) * RPV;
+        if constexpr (sizeof(REC) == 4) {
+          recs[4 * u + 0] = v[u].x;
+          recs[4 * u + 1] = v[u].y;
+          recs[4 * u + 2] = v[u].z;
+          recs[4 * u + 3] = v[u].w;
+        } else if constexpr (sizeof(REC) == 8) {
+          recs[2 * u + 0] = ((u64)v[u].y << 32) | v[u].x;
+          recs[2 * u + 1] = ((u64)v[u].w << 32) | v[u].z;
+        } else {
+          recs[u].lo = ((u64)v[u].y << 32) | v[u].x;
+          recs[u].hi = ((u64)v[u].w << 32) | v[u].z;
+        }
+#pragma unroll
+        for (u32 t = 0; t < RPV; t++)
+          if (first + t < nvalid) act |= 1u << (u * RPV + t);
+      }
+      f(recs, act);
     }
     __syncthreads();
   }

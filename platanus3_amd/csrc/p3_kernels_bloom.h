@@ -239,16 +239,19 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
   const u32 limit = TS - (TS >> 3);
   (void)CHUNK;
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
-  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC rec) {
-    u64 lo, hi = 0;
-    if constexpr (NW == 1) lo = rec;
-    else {
-      lo = rec.lo;
-      hi = rec.hi;
+  // slot / sub-bucket hash: the full 64-bit mix only when a sub-bucket split needs the scatter's bucket bits
+  auto slot_of = [&](u64 lo, u64 hi, bool& mine) -> u32 {
+    mine = true;
+    if (sbits) {
+      const u64 h = khash<NW>(lo, hi);
+      mine = ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
+      return (u32)(h >> 16) & (TS - 1);
     }
-    const u64 h = khash<NW>(lo, hi);
-    if (sbits && ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) != subsel) return;
-    u32 slot = (u32)(h >> 16) & (TS - 1);
+    u32 x = (u32)lo ^ (u32)(lo >> 32);
+    if (NW == 2) x ^= (u32)hi * 0x85EBCA6Bu ^ (u32)(hi >> 32);
+    return (x * 0x9E3779B1u) >> (32 - ts_log2);
+  };
+  auto slow_insert = [&](u64 lo, u64 hi, u32 slot) {
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       if constexpr (NW == 1) {
@@ -302,6 +305,33 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
       slot = (slot + 1) & (TS - 1);
     }
     if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
+  };
+  constexpr int NBATCH = 4 * (16 / sizeof(REC));
+  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+    // phase 1: independent home-slot reads for the whole batch; a duplicate (the common case) ends there
+    u64 lo[NBATCH], hi[NBATCH], cur[NBATCH];
+    u32 slot[NBATCH];
+#pragma unroll
+    for (int i = 0; i < NBATCH; i++) {
+      if constexpr (NW == 1) {
+        lo[i] = r[i];
+        hi[i] = 0;
+      } else {
+        lo[i] = r[i].lo;
+        hi[i] = r[i].hi;
+      }
+      bool mine;
+      slot[i] = slot_of(lo[i], hi[i], mine);
+      if (!mine) act &= ~(1u << i);
+      cur[i] = tlo[slot[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < NBATCH; i++) {
+      if (act & (1u << i)) {
+        if (NW == 1 && cur[i] == lo[i]) continue;
+        slow_insert(lo[i], hi[i], slot[i]);
+      }
+    }
   });
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -312,10 +342,16 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
   }
   __syncthreads();
   const u64 base = ((u64)sc[3] << 32) | sc[2];
-  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
-    const bool full = (NW == 1) ? (tlo[i] != ~0ULL) : (tstate[i] == 2u);
+  const u32 lane = threadIdx.x & 63;
+  for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
+    const u32 i = i0 + threadIdx.x;
+    const bool full = (i < TS) && ((NW == 1) ? (tlo[i] != ~0ULL) : (tstate[i] == 2u));
+    const unsigned long long bal = __ballot(full);
+    u32 wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&sc[1], (u32)__popcll(bal));
+    wbase = __shfl(wbase, 0, 64);
     if (full) {
-      const u32 idx = atomicAdd(&sc[1], 1u);
+      const u32 idx = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
       out_keys[(base + idx) * NW] = tlo[i];
       if (NW == 2) out_keys[(base + idx) * NW + 1] = thi[i];
     }
@@ -452,8 +488,11 @@ __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ p
   for (u32 i = threadIdx.x; i < words; i += blockDim.x) bm[i] = 0;
   __syncthreads();
   const u32 s = blockIdx.x;
-  bucket_for_each<u32>(part, seg_off, ghist, s, valid, sc + 8,
-                       [&](u32 r) { atomicOr(&bm[r >> 5], 1u << (r & 31)); });
+  bucket_for_each<u32>(part, seg_off, ghist, s, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if (act & (1u << i)) atomicOr(&bm[r[i] >> 5], 1u << (r[i] & 31));
+  });
   __syncthreads();
   const u64 w0 = (u64)s * words;
   for (u32 i = threadIdx.x; i < words; i += blockDim.x)

@@ -25,6 +25,7 @@
 #define P3_PART_THREADS 1024
 #define P3_TS_LOG2_MAX 14       // LDS count table: 16384 slots x (4 B remainder + 4 B count) = 128 KiB
 #define P3_EMPTY32 0xffffffffu
+#define P3_WQ_CAP 320u          // per-wave miss queue entries (63 left over + 4 x 64 new)
 #define P3_MIX_C 0x1E3779B97F5ULL  // odd, < 2^42
 #define P3_MASK42 ((1ULL << 42) - 1)
 
@@ -93,34 +94,64 @@ __global__ void __launch_bounds__(P3_NB) k_part_scan(const u32* __restrict__ ghi
                                                      u32* __restrict__ bucket_count, u64* __restrict__ totals) {
   __shared__ u32 padded[P3_NB];
   __shared__ u32 base[P3_NB];
-  const u32 pb = threadIdx.x;
-  u32 run = 0, exact = 0;
-  for (u32 wg = 0; wg < P3_NWG; wg++) {
-    u32 c = ghist[pb * P3_NWG + wg];
-    exact += c;
-    run += (c + 15u) & ~15u;
-  }
-  padded[pb] = run;
-  bucket_count[pb] = exact;
-  __syncthreads();
-  if (pb == 0) {
-    u64 acc = 0;
-    for (u32 i = 0; i < P3_NB; i++) {
-      base[i] = (u32)acc;
-      acc += padded[i];
+  static_assert(P3_NWG == 256, "one wave scans one 256-entry row with 4 entries per lane");
+  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
+  // pass 1: within-bucket exclusive offsets (coalesced 16-byte loads, wave scan)
+  for (u32 pb = wave; pb < P3_NB; pb += n_waves) {
+    const uint4 c = reinterpret_cast<const uint4*>(ghist + pb * P3_NWG)[lane];
+    const u32 p0 = (c.x + 15u) & ~15u, p1 = (c.y + 15u) & ~15u, p2 = (c.z + 15u) & ~15u, p3 = (c.w + 15u) & ~15u;
+    u32 incl = p0 + p1 + p2 + p3, exact = c.x + c.y + c.z + c.w;
+    for (int off = 1; off < 64; off <<= 1) {
+      const u32 t = __shfl_up(incl, off, 64);
+      if ((int)lane >= off) incl += t;
     }
-    totals[1] = acc;
+    for (int off = 32; off > 0; off >>= 1) exact += __shfl_down(exact, off, 64);
+    const u32 excl = incl - (p0 + p1 + p2 + p3);
+    reinterpret_cast<uint4*>(seg_off + pb * P3_NWG)[lane] = make_uint4(excl, excl + p0, excl + p0 + p1, excl + p0 + p1 + p2);
+    if (lane == 63) padded[pb] = incl;
+    if (lane == 0) bucket_count[pb] = exact;
   }
   __syncthreads();
-  run = base[pb];
-  for (u32 wg = 0; wg < P3_NWG; wg++) {
-    u32 c = ghist[pb * P3_NWG + wg];
-    seg_off[pb * P3_NWG + wg] = run;
-    run += (c + 15u) & ~15u;
+  // exclusive scan of the 1024 padded bucket sizes (Hillis-Steele in LDS)
+  const u32 t = threadIdx.x;
+  u32 v = padded[t];
+  base[t] = v;
+  __syncthreads();
+  for (u32 off = 1; off < P3_NB; off <<= 1) {
+    const u32 add = (t >= off) ? base[t - off] : 0;
+    __syncthreads();
+    base[t] += add;
+    __syncthreads();
   }
-  // totals[0], totals[2] via atomics (1024 threads, once)
-  atomicAdd((unsigned long long*)&totals[0], (unsigned long long)exact);
-  atomicMax((unsigned long long*)&totals[2], (unsigned long long)exact);
+  const u32 incl_t = base[t];
+  __syncthreads();
+  base[t] = incl_t - v;
+  if (t == P3_NB - 1) totals[1] = incl_t;
+  {
+    u64 e = bucket_count[t];  // written by lane 0 of some wave of this block before the barrier above
+    u64 mx = e;
+    for (int off = 32; off > 0; off >>= 1) {
+      e += __shfl_down(e, off, 64);
+      const u64 o = __shfl_down(mx, off, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+      atomicAdd((unsigned long long*)&totals[0], (unsigned long long)e);
+      atomicMax((unsigned long long*)&totals[2], (unsigned long long)mx);
+    }
+  }
+  __syncthreads();
+  // pass 2: add the bucket base
+  for (u32 pb = wave; pb < P3_NB; pb += n_waves) {
+    uint4* row = reinterpret_cast<uint4*>(seg_off + pb * P3_NWG);
+    uint4 o = row[lane];
+    const u32 bb = base[pb];
+    o.x += bb;
+    o.y += bb;
+    o.z += bb;
+    o.w += bb;
+    row[lane] = o;
+  }
 }
 
 // ---- k_part_scatter ------------------------------------------------------------------------------------
@@ -276,10 +307,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   const u32 lane = threadIdx.x & 63;
   const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
-  bucket_for_each<u32>(part, seg_off, ghist, pb, valid, sc + 8, [&](u32 r) {
-    if ((r >> rem_bits) != subsel) return;
-    const u32 rem = r & rem_mask;
-    u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
+  auto slow_insert = [&](u32 rem, u32 slot) {
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       u32 old = tkey[slot];
@@ -296,7 +324,48 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
       slot = (slot + 1) & (TS - 1);
     }
     if (!placed) s_ovf = 1;  // table (nearly) full: the host re-splits or falls back
+  };
+  // Probing is data dependent, so a per-record probe loop costs the LONGEST chain among the 64 lanes for
+  // every record.  Instead: all lanes do the (uniform) home-slot check; misses go to a per-wave LDS queue
+  // and are drained 64 at a time, one item per lane, so the divergent loop always runs with full lanes.
+  u32* wq = reinterpret_cast<u32*>(valid + P3_VALID_CAP) + (threadIdx.x >> 6) * P3_WQ_CAP;
+  u32 qn = 0;  // wave-uniform
+  const unsigned long long lt_mask = (1ULL << lane) - 1;
+  bucket_for_each<u32>(part, seg_off, ghist, pb, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      u32 rem[4], slot[4], cur[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int i = 4 * g4 + t;
+        rem[t] = r[i] & rem_mask;
+        slot[t] = (rem[t] * 0x9E3779B1u) >> (32 - ts_log2);
+        cur[t] = tkey[slot[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int i = 4 * g4 + t;
+        const bool mine = (act & (1u << i)) && ((r[i] >> rem_bits) == subsel);
+        const bool hit = mine && cur[t] == rem[t];
+        if (hit) atomicAdd(&tcnt[slot[t]], 1u);
+        const bool miss = mine && !hit;
+        const unsigned long long bal = __ballot(miss);
+        if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = rem[t];
+        qn += (u32)__popcll(bal);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (qn >= 64) {
+        qn -= 64;
+        const u32 item = wq[qn + lane];
+        slow_insert(item, (item * 0x9E3779B1u) >> (32 - ts_log2));
+      }
+    }
   });
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < qn) {
+    const u32 item = wq[lane];
+    slow_insert(item, (item * 0x9E3779B1u) >> (32 - ts_log2));
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (s_ovf) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
@@ -307,11 +376,17 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   __syncthreads();
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
   u32 my_solid = 0, my_max = 0;
-  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
-    const u32 rem = tkey[i];
-    if (rem != P3_EMPTY32) {
+  for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {  // TS is a multiple of the block size or smaller than it
+    const u32 i = i0 + threadIdx.x;
+    const u32 rem = (i < TS) ? tkey[i] : P3_EMPTY32;
+    const bool full = rem != P3_EMPTY32;
+    const unsigned long long bal = __ballot(full);
+    u32 wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&s_cur, (u32)__popcll(bal));
+    wbase = __shfl(wbase, 0, 64);
+    if (full) {
       const u32 c = tcnt[i];
-      const u32 idx = atomicAdd(&s_cur, 1u);
+      const u32 idx = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
       const u64 g = ((u64)pb << 32) | ((u64)subsel << rem_bits) | rem;
       out_keys[base + idx] = unmix42(g);
       out_counts[base + idx] = c;
@@ -389,6 +464,8 @@ __device__ __forceinline__ bool solid_lookup(const u32* __restrict__ solid, u32 
 }
 
 // ---- k_gate_regions ---------------------------------------------------------------------------------------
+// One probe chain per window.  (A variant that issued 16 probes per lane per round measured 25 % SLOWER: the
+// kernel is bound by Infinity-Cache line traffic of the random table reads, not by their latency.)
 __global__ void __launch_bounds__(256) k_gate_regions(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, u64 n_words,
                                                       const u32* __restrict__ solid, u32 sbits, u32 rs_log2,

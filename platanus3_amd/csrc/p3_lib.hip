@@ -328,7 +328,7 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
     const u32 nsb = P3_NB << sbits;
     if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
     HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP;
+    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     HIPCHK(c, hipFuncSetAttribute((const void*)k_part_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0_ = nullptr, e1_ = nullptr;
     if (c->profiling) {
