@@ -306,33 +306,73 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
     }
     if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
   };
+  // Same structure as k_part_count: uniform home-slot check, misses through a per-wave LDS queue that is
+  // drained 64 items at a time so the data-dependent probe loop always runs with full lanes.
   constexpr int NBATCH = 4 * (16 / sizeof(REC));
-  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
-    // phase 1: independent home-slot reads for the whole batch; a duplicate (the common case) ends there
-    u64 lo[NBATCH], hi[NBATCH], cur[NBATCH];
-    u32 slot[NBATCH];
-#pragma unroll
-    for (int i = 0; i < NBATCH; i++) {
-      if constexpr (NW == 1) {
-        lo[i] = r[i];
-        hi[i] = 0;
-      } else {
-        lo[i] = r[i].lo;
-        hi[i] = r[i].hi;
-      }
-      bool mine;
-      slot[i] = slot_of(lo[i], hi[i], mine);
-      if (!mine) act &= ~(1u << i);
-      cur[i] = tlo[slot[i]];
+  constexpr int G = (NW == 1) ? 4 : 2;              // records per lane between drains
+  constexpr u32 QCAP = 64 * G + 64;                 // 63 left over + 64*G new
+  REC* wq = reinterpret_cast<REC*>(valid + P3_VALID_CAP) + (threadIdx.x >> 6) * QCAP;
+  u32 qn = 0;  // wave-uniform
+  const u32 lane_id = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ULL << lane_id) - 1;
+  auto drain_item = [&](const REC& it) {
+    u64 lo, hi = 0;
+    if constexpr (NW == 1) lo = it;
+    else {
+      lo = it.lo;
+      hi = it.hi;
     }
+    bool mine;
+    const u32 slot = slot_of(lo, hi, mine);
+    slow_insert(lo, hi, slot);
+  };
+  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
 #pragma unroll
-    for (int i = 0; i < NBATCH; i++) {
-      if (act & (1u << i)) {
-        if (NW == 1 && cur[i] == lo[i]) continue;
-        slow_insert(lo[i], hi[i], slot[i]);
+    for (int g0 = 0; g0 < NBATCH; g0 += G) {
+      u64 lo[G], hi[G], cur_lo[G], cur_hi[G];
+      u32 slot[G], st[G];
+      bool mine[G];
+#pragma unroll
+      for (int t = 0; t < G; t++) {
+        if constexpr (NW == 1) {
+          lo[t] = r[g0 + t];
+          hi[t] = 0;
+        } else {
+          lo[t] = r[g0 + t].lo;
+          hi[t] = r[g0 + t].hi;
+        }
+        slot[t] = slot_of(lo[t], hi[t], mine[t]);
+        cur_lo[t] = tlo[slot[t]];
+        if constexpr (NW == 2) {
+          st[t] = tstate[slot[t]];
+          cur_hi[t] = thi[slot[t]];
+        } else {
+          st[t] = 2;
+          cur_hi[t] = 0;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < G; t++) {
+        const bool want = mine[t] && (act & (1u << (g0 + t)));
+        const bool hit = want && st[t] == 2u && cur_lo[t] == lo[t] && cur_hi[t] == hi[t];
+        const bool miss = want && !hit;
+        const unsigned long long bal = __ballot(miss);
+        if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = r[g0 + t];
+        qn += (u32)__popcll(bal);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (qn >= 64) {
+        qn -= 64;
+        const REC it = wq[qn + lane_id];
+        drain_item(it);
       }
     }
   });
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane_id < qn) {
+    const REC it = wq[lane_id];
+    drain_item(it);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (sc[6]) atomicAdd((unsigned long long*)&gstats[3], 1ULL);

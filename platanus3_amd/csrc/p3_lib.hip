@@ -458,7 +458,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       }
       const u32 nsb = P3_NB << sbits;
       HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VALID_CAP;
+      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VALID_CAP +
+                         16 * (NW == 1 ? 320 * 8 : 192 * 16);
       LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), nsb, 1024, lds, (const REC*)c->kpart.p,
                  (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st);
       HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
