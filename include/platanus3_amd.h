@@ -130,6 +130,49 @@ int p3_kernel_stat_count(p3_ctx* ctx);
 int p3_kernel_stat(p3_ctx* ctx, int idx, char* name64, uint64_t* launches, double* total_ms);
 int p3_reset_kernel_stats(p3_ctx* ctx);
 
+/* ---- multi-rank protocol ------------------------------------------------------
+ * One context per rank (one process per GPU).  Reads are sharded by index; canonical 21-mers are routed to
+ * the rank that owns their hash bucket (contiguous ranges of the 1024 buckets); the owner counts them and
+ * builds the solid-key regions of its sub-buckets; regions are all-gathered; every rank then gates its own
+ * reads and builds a full-size PARTIAL Bloom vector that is OR-merged (slice exchange + local OR +
+ * all-gather; RCCL has no OR reduction).  The library does the compute; the HOST moves the bytes (RCCL
+ * directly, or torch.distributed as platanus3_amd/pipeline.py does) between the device buffers below.
+ *
+ *   p3_mr_config -> p3_load_reads -> p3_mr_count_partition -> p3_mr_count_send_layout
+ *     [all-to-all of per-destination record counts, then of the blobs and their descriptor rows]
+ *   -> p3_mr_count_recv_alloc (before the data all-to-all) -> p3_mr_count_owned(sbits)
+ *     [all-reduce MAX of `overflowed`: if set, every rank repeats with sbits+1; all-reduce MAX of max_solid_sb]
+ *   -> p3_mr_solid_build(p3_rs_log2_for(max)) [all-gather of the owned byte range of d_solid]
+ *   -> p3_make_bloom (rank-local) -> p3_mr_bloom_buffer [all-to-all of equal word chunks into scratch,
+ *      p3_mr_or_reduce into the own chunk, all-gather] -> exports as in the single-rank case
+ *      (p3_export_counts returns this rank's shard of the table; the global table is the disjoint union). */
+#define P3_MAX_RANKS 64
+typedef struct {
+  void* d_part;      /* uint32 records; the blob for rank d is records [rec_off[d], rec_off[d+1])          */
+  void* d_ghist;     /* [1024][row_u32] uint32 counts; rows [d*rows_per_rank, (d+1)*rows_per_rank) go to d   */
+  void* d_segoff;    /* same shape: record offsets of the segments (relative to this rank's d_part)           */
+  uint64_t rec_off[P3_MAX_RANKS + 1];
+  uint32_t rows_per_rank, row_u32;
+} p3_mr_send_layout;
+int p3_mr_config(p3_ctx* ctx, uint32_t rank, uint32_t n_ranks); /* n_ranks must divide 1024 */
+int p3_mr_count_partition(p3_ctx* ctx);
+int p3_mr_count_send_layout(p3_ctx* ctx, p3_mr_send_layout* out);
+/* recv_records[s] = records arriving from rank s (multiples of 16).  The blob of rank s must land at record
+ * offset sum(recv_records[0..s)) of *d_rpart; its descriptor rows at [s][rows_per_rank][row_u32] of
+ * *d_rghist / *d_rsegoff. */
+int p3_mr_count_recv_alloc(p3_ctx* ctx, const uint64_t* recv_records, void** d_rpart, void** d_rghist,
+                           void** d_rsegoff);
+int p3_mr_initial_sbits(p3_ctx* ctx, uint32_t* sbits);
+int p3_mr_count_owned(p3_ctx* ctx, uint32_t sbits, int* overflowed, uint64_t* max_solid_sb);
+uint32_t p3_rs_log2_for(uint64_t max_solid_sb);
+int p3_mr_solid_build(p3_ctx* ctx, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes,
+                      uint64_t* owned_bytes, uint64_t* total_bytes);
+int p3_mr_bloom_buffer(p3_ctx* ctx, void** d_words, uint64_t* n_words_padded /* multiple of n_ranks */);
+/* dst[i] = OR over s of src[s*stride_words + i] (uint64 words, device pointers) */
+int p3_mr_or_reduce(p3_ctx* ctx, void* d_dst, const void* d_src, uint64_t n_words, uint32_t n_src,
+                    uint64_t stride_words);
+int p3_mr_alloc_scratch(p3_ctx* ctx, uint64_t bytes, void** d_ptr);
+
 /* ---- synthetic workload (plain C, CPU) -------------------------------------- */
 uint64_t p3_synth_genome_length(uint64_t total_reads, uint32_t read_len, uint32_t coverage);
 int p3_synth_reads(uint64_t seed, uint64_t total_reads, uint64_t first_read, uint64_t n_reads,

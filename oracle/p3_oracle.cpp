@@ -250,6 +250,27 @@ int p3o_count_short(const char* bases, const uint64_t* offsets, uint64_t n_reads
   return n > cap ? 3 : 0;
 }
 
+// every valid window's canonical 21-mer, in read order (C1's enumeration without the counting)
+int p3o_list_canon21(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len,
+                     uint64_t* out, uint64_t cap, uint64_t* n_out) {
+  uint64_t n = 0;
+  for (uint64_t r = 0; r < n_reads; r++) {
+    const char* s = bases + offsets[r];
+    const uint64_t L = offsets[r + 1] - offsets[r];
+    if (L < min_len || L < 21) continue;
+    Roller ro(21);
+    for (uint64_t i = 0; i < L; i++) {
+      ro.push(s[i]);
+      if (i >= 20) {
+        if (n < cap) out[n] = (uint64_t)ro.canon();
+        n++;
+      }
+    }
+  }
+  *n_out = n;
+  return n > cap ? 3 : 0;
+}
+
 uint64_t p3o_gate_flags(const char* read, uint64_t L, const uint64_t* keys, const uint64_t* counts,
                         uint64_t n_keys, int k, uint8_t* flags) {
   if (L < (uint64_t)k || L < 21) return 0;

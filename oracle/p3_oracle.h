@@ -43,6 +43,11 @@ void p3o_estimate_bloom(uint64_t all_bases, int k, uint64_t m_in, uint64_t* m_ou
 int p3o_count_short(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len,
                     uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n_out);
 
+/* canonical 21-mer of every valid window, in read order (used by the CPU stand-in backend of the
+ * multi-rank orchestration tests) */
+int p3o_list_canon21(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len,
+                     uint64_t* out, uint64_t cap, uint64_t* n_out);
+
 /* G2: gate + Bloom build + seeds.  (keys,counts) = C1's output (sorted).  bloom_words: ceil(m/64)
  * words, bit i = words[i/64]>>(i%64)&1.  seeds: n_seeds * k chars, sorted by string (std::set order).
  * n_inserted = number of BF::add calls.  count_overflow set if any looked-up count >= 2^31 (G1 int quirk). */

@@ -63,6 +63,7 @@ class Oracle:
         L.p3o_estimate_bloom.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.p3o_count_short.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, _u64p, _u64p, C.c_uint64,
                                       C.POINTER(C.c_uint64)]
+        L.p3o_list_canon21.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, _u64p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.p3o_make_bf.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, _u64p, _u64p, C.c_uint64, C.c_int,
                                   C.c_uint64, C.c_int, _u64p, _u8p, C.c_uint64, C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -150,6 +151,15 @@ class Oracle:
         rc = self.lib.p3o_count_short(bases, offs, n_reads, min_len, keys, counts, cap, C.byref(n))
         assert rc == 0, rc
         return keys[: n.value].copy(), counts[: n.value].copy()
+
+    def list_canon21(self, reads, min_len=21):
+        bases, offs = _flat(reads)
+        cap = max(1, int(bases.size))
+        out = np.zeros(cap, np.uint64)
+        n = C.c_uint64()
+        rc = self.lib.p3o_list_canon21(bases, offs, offs.size - 1, min_len, out, cap, C.byref(n))
+        assert rc == 0, rc
+        return out[: n.value].copy()
 
     def make_bf(self, reads, keys, counts, k, m, H, min_len=None):
         bases, offs = _flat(reads)

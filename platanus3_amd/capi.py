@@ -35,6 +35,14 @@ class Timings(C.Structure):
                 ("ms_seeds", C.c_float), ("ms_total", C.c_float)]
 
 
+P3_MAX_RANKS = 64
+
+
+class MrSendLayout(C.Structure):
+    _fields_ = [("d_part", C.c_void_p), ("d_ghist", C.c_void_p), ("d_segoff", C.c_void_p),
+                ("rec_off", C.c_uint64 * (P3_MAX_RANKS + 1)), ("rows_per_rank", C.c_uint32), ("row_u32", C.c_uint32)]
+
+
 _lib = None
 
 
@@ -74,6 +82,18 @@ def load(build=False):
     L.p3_get_bloom_stats.argtypes = [vp, C.POINTER(BloomStats)]
     L.p3_bloom_query.argtypes = [vp, vp, u64, vp]
     L.p3_run_pass.argtypes = [vp, u32, u64, u32]
+    L.p3_mr_config.argtypes = [vp, u32, u32]
+    L.p3_mr_count_partition.argtypes = [vp]
+    L.p3_mr_count_send_layout.argtypes = [vp, C.POINTER(MrSendLayout)]
+    L.p3_mr_count_recv_alloc.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.p3_mr_initial_sbits.argtypes = [vp, C.POINTER(u32)]
+    L.p3_mr_count_owned.argtypes = [vp, u32, C.POINTER(C.c_int), C.POINTER(u64)]
+    L.p3_rs_log2_for.restype = u32
+    L.p3_rs_log2_for.argtypes = [u64]
+    L.p3_mr_solid_build.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.p3_mr_bloom_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    L.p3_mr_or_reduce.argtypes = [vp, vp, vp, u64, u32, u64]
+    L.p3_mr_alloc_scratch.argtypes = [vp, u64, C.POINTER(vp)]
     L.p3_last_timings.argtypes = [vp, C.POINTER(Timings)]
     L.p3_kernel_stat_count.argtypes = [vp]
     L.p3_kernel_stat.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
@@ -105,6 +125,7 @@ class Context:
             raise P3Error(rc, "p3_create(device=%d): no usable HIP device?" % device)
         self.h = h
         self.k = None
+        self.n_ranks = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -191,6 +212,58 @@ class Context:
         out = np.zeros(max(1, n), np.uint8)
         self._chk(self.L.p3_bloom_query(self.h, keys.ctypes.data, n, out.ctypes.data))
         return out[:n]
+
+    # ---- multi-rank protocol (device pointers are returned as plain ints) ----------------------------
+    def mr_config(self, rank, n_ranks):
+        self._chk(self.L.p3_mr_config(self.h, rank, n_ranks))
+        self.n_ranks = n_ranks
+
+    def mr_count_partition(self):
+        self._chk(self.L.p3_mr_count_partition(self.h))
+
+    def mr_count_send_layout(self):
+        lay = MrSendLayout()
+        self._chk(self.L.p3_mr_count_send_layout(self.h, C.byref(lay)))
+        n = self.n_ranks
+        return dict(d_part=lay.d_part, d_ghist=lay.d_ghist, d_segoff=lay.d_segoff,
+                    rec_off=[int(lay.rec_off[i]) for i in range(n + 1)], rows=lay.rows_per_rank, row_u32=lay.row_u32)
+
+    def mr_count_recv_alloc(self, recv_records):
+        arr = (C.c_uint64 * len(recv_records))(*[int(x) for x in recv_records])
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.p3_mr_count_recv_alloc(self.h, arr, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def mr_initial_sbits(self):
+        v = C.c_uint32()
+        self._chk(self.L.p3_mr_initial_sbits(self.h, C.byref(v)))
+        return v.value
+
+    def mr_count_owned(self, sbits):
+        ovf, mx = C.c_int(), C.c_uint64()
+        self._chk(self.L.p3_mr_count_owned(self.h, sbits, C.byref(ovf), C.byref(mx)))
+        return ovf.value, mx.value
+
+    def rs_log2_for(self, max_solid):
+        return int(self.L.p3_rs_log2_for(max_solid))
+
+    def mr_solid_build(self, rs_log2):
+        p, off, own, tot = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self.L.p3_mr_solid_build(self.h, rs_log2, C.byref(p), C.byref(off), C.byref(own), C.byref(tot)))
+        return p.value, off.value, own.value, tot.value
+
+    def mr_bloom_buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.p3_mr_bloom_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def mr_or_reduce(self, d_dst, d_src, n_words, n_src, stride_words):
+        self._chk(self.L.p3_mr_or_reduce(self.h, d_dst, d_src, n_words, n_src, stride_words))
+
+    def mr_alloc_scratch(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.L.p3_mr_alloc_scratch(self.h, nbytes, C.byref(p)))
+        return p.value
 
     # ---- timings ------------------------------------------------------------------------------------
     def set_profiling(self, on):

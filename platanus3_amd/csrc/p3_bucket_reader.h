@@ -26,6 +26,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
     my_off = seg_off[pb * P3_NWG + threadIdx.x];
     my_n = ghist[pb * P3_NWG + threadIdx.x];
   }
+  __syncthreads();  // sc2 / valid may still be in use by a previous call
   if (threadIdx.x == 0) sc2[0] = my_off;
   if (threadIdx.x == P3_NWG - 1) sc2[1] = my_off + ((my_n + 15u) & ~15u);
   __syncthreads();

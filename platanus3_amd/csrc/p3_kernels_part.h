@@ -271,8 +271,13 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __r
 // ---- k_part_count: one workgroup per sub-bucket ---------------------------------------------------------
 // gstats[0] = distinct cursor, [1] = solid total, [2] = max count, [3] = overflow flag, [4] = max solid per
 // sub-bucket.  sb_info[sb] = {base, n_distinct, n_solid, 0}
+// Multi-rank form: the records of an owned bucket arrive as n_src blobs (one per source rank, blob s at record
+// offset roff[s] of `part`), each with its own [rows][NWG] descriptor tables stacked in seg_off / ghist; a
+// source's offsets are relative to its own buffer, so they are rebased by its first descriptor.  With one
+// rank: n_src = 1, rows = NB, roff[0] = 0, first_pb = 0 and `part` is the local partition itself.
 __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ part, const u32* __restrict__ seg_off,
-                                                     const u32* __restrict__ ghist, u32 sbits, u32 ts_log2,
+                                                     const u32* __restrict__ ghist, const u64* __restrict__ roff,
+                                                     u32 n_src, u32 rows, u32 first_pb, u32 sbits, u32 ts_log2,
                                                      u64* __restrict__ out_keys, u32* __restrict__ out_counts,
                                                      uint4* __restrict__ sb_info, u64* __restrict__ gstats) {
   extern __shared__ __align__(16) u32 lds[];
@@ -299,8 +304,9 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
     s_ovf = 0;
   }
   __syncthreads();
-  const u32 sb = blockIdx.x;
-  const u32 pb = sb >> sbits;
+  const u32 sb = blockIdx.x;           // owned (local) sub-bucket index
+  const u32 pb_local = sb >> sbits;
+  const u32 pb = first_pb + pb_local;  // global bucket id (key reconstruction)
   const u32 subsel = sb & ((1u << sbits) - 1);
   const u32 rem_bits = 32 - sbits;
   const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
@@ -331,7 +337,10 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   u32* wq = reinterpret_cast<u32*>(valid + P3_VALID_CAP) + (threadIdx.x >> 6) * P3_WQ_CAP;
   u32 qn = 0;  // wave-uniform
   const unsigned long long lt_mask = (1ULL << lane) - 1;
-  bucket_for_each<u32>(part, seg_off, ghist, pb, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
+  for (u32 src = 0; src < n_src; src++) {
+  const u32 row = src * rows + pb_local;
+  const u32* part_src = part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
+  bucket_for_each<u32>(part_src, seg_off, ghist, row, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
 #pragma unroll
     for (int g4 = 0; g4 < 4; g4++) {
       u32 rem[4], slot[4], cur[4];
@@ -361,6 +370,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
       }
     }
   });
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < qn) {
     const u32 item = wq[lane];
@@ -423,8 +433,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
 
 // ---- k_solid_regions: region[sb] = open-addressing table (rs slots) of the solid remainders of sub-bucket sb
 __global__ void __launch_bounds__(256) k_solid_regions(const u64* __restrict__ keys, const u32* __restrict__ counts,
-                                                       const uint4* __restrict__ sb_info, u32 sbits, u32 rs_log2,
-                                                       u32* __restrict__ solid) {
+                                                       const uint4* __restrict__ sb_info, u32 first_sb, u32 sbits,
+                                                       u32 rs_log2, u32* __restrict__ solid) {
   extern __shared__ __align__(16) u32 lds[];
   const u32 RS = 1u << rs_log2;
   for (u32 i = threadIdx.x; i < RS; i += blockDim.x) lds[i] = P3_EMPTY32;
@@ -445,7 +455,7 @@ __global__ void __launch_bounds__(256) k_solid_regions(const u64* __restrict__ k
     }
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i < RS; i += blockDim.x) solid[(u64)sb * RS + i] = lds[i];
+  for (u32 i = threadIdx.x; i < RS; i += blockDim.x) solid[(u64)(first_sb + sb) * RS + i] = lds[i];
 }
 
 __device__ __forceinline__ bool solid_lookup(const u32* __restrict__ solid, u32 sbits, u32 rs_log2, u64 key) {

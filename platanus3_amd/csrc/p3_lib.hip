@@ -68,6 +68,12 @@ struct p3_ctx {
   int tsk_log2_opt = 13;    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0;
   DevBuf kpart, dkeys, ppart;
+  // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
+  u32 rank = 0, n_ranks = 1;
+  DevBuf rx_roff, rx_part_buf, rx_ghist_buf, rx_segoff_buf, or_tmp;
+  void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
+  u64 rx_records = 0;
+  bool mr_partitioned = false;
   int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
 
@@ -272,119 +278,118 @@ int do_count_direct(p3_ctx* c) {
 // limits of the partitioned form: 32-bit record indices
 bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG * P3_NB < (1ull << 31); }
 
-// Partitioned count.  Returns P3_OK with *overflowed = true when an LDS table overflowed even at the
-// largest sub-bucket split (caller then falls back to the direct form).
-int do_count_part(p3_ctx* c, bool* overflowed) {
+// ---- partitioned count, in the three steps the multi-rank protocol interleaves with its exchanges ----------
+// (1) local partition of this rank's canonical 21-mers by bucket
+int part_local(p3_ctx* c) {
   int rc;
-  *overflowed = false;
   const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
   if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
   if ((rc = ensure(c, c->part, max_records * 4))) return rc;
-  u64 maxd = c->n_bases + 1;
-  if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
-  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
   LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
   LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
          (u32*)c->bucket_count.p, st + 5);  // totals at st[5..7]
-  {
-    const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCHK(c, hipFuncSetAttribute((const void*)k_part_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
-    hipEvent_t e0_ = nullptr, e1_ = nullptr;
-    if (c->profiling) {
-      HIPCHK(c, hipEventCreate(&e0_));
-      HIPCHK(c, hipEventCreate(&e1_));
-      HIPCHK(c, hipEventRecord(e0_, c->stream));
-    }
-    hipLaunchKernelGGL(k_part_scatter, dim3(P3_NWG), dim3(P3_PART_THREADS), lds, c->stream, (const u64*)c->fw.p,
-                       (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p,
-                       (u32*)c->part.p);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) {
-      HIPCHK(c, hipEventRecord(e1_, c->stream));
-      KStat* s_ = stat_for(c, "k_part_scatter");
-      s_->launches++;
-      s_->pending.push_back({e0_, e1_});
-    }
-  }
-  // sub-bucket split: aim at <= 64 Ki instances per LDS table; grow it if a table overflows
-  u32 sbits = 1;
-  while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > 65536) sbits++;
+  const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
+  LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
+             (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
+  return P3_OK;
+}
+
+// (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
+int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
+  int rc;
+  const u32 rows = P3_NB / c->n_ranks;
+  const u32 nsb = rows << sbits;
+  // worst case one entry per received record
+  u64 maxd = c->rx_records + 1;
+  if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
+  const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
+  LAUNCH_LDS(c, "k_part_count", k_part_count, nsb, 1024, lds, (const u32*)c->rx_part, (const u32*)c->rx_segoff,
+             (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows, c->rank * rows, sbits, ts_log2,
+             (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st);
   u64 h[8];
-  for (;; sbits++) {
-    if (sbits > 5) {
-      *overflowed = true;
-      return P3_OK;
-    }
-    const u32 nsb = P3_NB << sbits;
-    if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
-    HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-    const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_part_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipEvent_t e0_ = nullptr, e1_ = nullptr;
-    if (c->profiling) {
-      HIPCHK(c, hipEventCreate(&e0_));
-      HIPCHK(c, hipEventCreate(&e1_));
-      HIPCHK(c, hipEventRecord(e0_, c->stream));
-    }
-    hipLaunchKernelGGL(k_part_count, dim3(nsb), dim3(1024), lds, c->stream, (const u32*)c->part.p,
-                       (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->ckeys.p,
-                       (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) {
-      HIPCHK(c, hipEventRecord(e1_, c->stream));
-      KStat* s_ = stat_for(c, "k_part_count");
-      s_->launches++;
-      s_->pending.push_back({e0_, e1_});
-    }
-    HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (h[3] == 0) break;  // no LDS table overflowed
-  }
+  HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *overflowed = h[3] != 0;
+  *max_solid_sb = h[4];
   c->sbits = sbits;
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[2];
-  c->cstats.n_windows = h[5];
-  // solid regions: slots = pow2 >= 1.6 * (largest number of solid keys in one sub-bucket), >= 64
-  u64 want = h[4] + (h[4] * 3) / 5 + 1;
-  u32 rs_log2 = 6;
-  while ((1ull << rs_log2) < want) rs_log2++;
-  c->rs_log2 = rs_log2;
-  const u32 nsb = P3_NB << sbits;
-  if ((rc = ensure(c, c->solid, ((size_t)nsb << rs_log2) * 4))) return rc;
-  {
-    const size_t lds = ((size_t)1 << rs_log2) * 4;
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_solid_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipEvent_t e0_ = nullptr, e1_ = nullptr;
-    if (c->profiling) {
-      HIPCHK(c, hipEventCreate(&e0_));
-      HIPCHK(c, hipEventCreate(&e1_));
-      HIPCHK(c, hipEventRecord(e0_, c->stream));
-    }
-    hipLaunchKernelGGL(k_solid_regions, dim3(nsb), dim3(256), lds, c->stream, (const u64*)c->ckeys.p,
-                       (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, sbits, rs_log2, (u32*)c->solid.p);
-    HIPCHK(c, hipGetLastError());
-    if (c->profiling) {
-      HIPCHK(c, hipEventRecord(e1_, c->stream));
-      KStat* s_ = stat_for(c, "k_solid_regions");
-      s_->launches++;
-      s_->pending.push_back({e0_, e1_});
-    }
-  }
-  c->count_mode = 2;
+  c->cstats.n_windows = h[5];  // this rank's windows (local partition)
   c->ccounts_u32 = true;
+  return P3_OK;
+}
+
+// (3) solid regions of the owned sub-buckets, written in place into the full-size table
+int solid_build(p3_ctx* c, u32 rs_log2) {
+  int rc;
+  const u32 rows = P3_NB / c->n_ranks;
+  const u32 nsb_owned = rows << c->sbits;
+  const u32 nsb_all = P3_NB << c->sbits;
+  c->rs_log2 = rs_log2;
+  if ((rc = ensure(c, c->solid, ((size_t)nsb_all << rs_log2) * 4))) return rc;
+  const size_t lds = ((size_t)1 << rs_log2) * 4;
+  LAUNCH_LDS(c, "k_solid_regions", k_solid_regions, nsb_owned, 256, lds, (const u64*)c->ckeys.p,
+             (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, c->rank * nsb_owned, c->sbits, rs_log2,
+             (u32*)c->solid.p);
+  c->count_mode = 2;
   c->counted = true;
   return P3_OK;
+}
+
+u32 initial_sbits(u64 total_windows_bound) {
+  u32 sbits = 1;  // aim at <= 64 Ki instances per LDS table
+  while (sbits < 5 && total_windows_bound / ((u64)P3_NB << sbits) > 65536) sbits++;
+  return sbits;
+}
+
+u32 rs_log2_for(u64 max_solid_sb) {
+  // slots = pow2 >= 1.6 * (largest number of solid keys in one sub-bucket), >= 64
+  u64 want = max_solid_sb + (max_solid_sb * 3) / 5 + 1;
+  u32 rs_log2 = 6;
+  while ((1ull << rs_log2) < want) rs_log2++;
+  return rs_log2;
+}
+
+int set_rx_local(p3_ctx* c) {
+  int rc;
+  if ((rc = ensure(c, c->rx_roff, 8 * 16))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->rx_roff.p, 0, 8 * 16, c->stream));
+  c->rx_part = c->part.p;
+  c->rx_ghist = c->ghist.p;
+  c->rx_segoff = c->seg_off.p;
+  c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+  return P3_OK;
+}
+
+// Single-rank partitioned count.  *overflowed = true when an LDS table overflowed even at the largest
+// sub-bucket split (caller then falls back to the direct form).
+int do_count_part(p3_ctx* c, bool* overflowed) {
+  int rc;
+  *overflowed = false;
+  if ((rc = part_local(c))) return rc;
+  if ((rc = set_rx_local(c))) return rc;
+  u64 max_solid = 0;
+  for (u32 sbits = initial_sbits(c->n_words * 32);; sbits++) {
+    if (sbits > 5) {
+      *overflowed = true;
+      return P3_OK;
+    }
+    bool ovf = false;
+    if ((rc = count_owned(c, sbits, &ovf, &max_solid))) return rc;
+    if (!ovf) break;
+  }
+  return solid_build(c, rs_log2_for(max_solid));
 }
 
 int do_count(p3_ctx* c) {
@@ -409,15 +414,16 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   int rc;
   const u64 nwa = c->n_words + P3_PAD_WORDS;
   const u64 bwords = (m + 63) / 64;
+  const u64 bwords_padded = (bwords + c->n_ranks - 1) / c->n_ranks * c->n_ranks;
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   if ((rc = ensure(c, c->P, nwa * 4))) return rc;
-  if ((rc = ensure(c, c->bloom, bwords * 8))) return rc;
+  if ((rc = ensure(c, c->bloom, bwords_padded * 8))) return rc;
   if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
   if ((rc = ensure(c, c->seed_valid, c->n_reads + 1))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (c->count_mode == 2) {
@@ -532,6 +538,16 @@ int check_k(p3_ctx* c, u32 k) {
 
 }  // namespace
 
+__global__ void __launch_bounds__(256) k_or_reduce(u64* __restrict__ dst, const u64* __restrict__ src, u64 n_words,
+                                                   u32 n_src, u64 stride) {
+  const u64 step = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += step) {
+    u64 v = 0;
+    for (u32 s = 0; s < n_src; s++) v |= src[s * stride + i];
+    dst[i] = v;
+  }
+}
+
 extern "C" {
 
 int p3_device_count(void) {
@@ -573,7 +589,8 @@ int p3_destroy(p3_ctx* c) {
     }
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
-                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart};
+                    &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart, &c->rx_roff, &c->rx_part_buf, &c->rx_ghist_buf, &c->rx_segoff_buf,
+                    &c->or_tmp};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -655,9 +672,153 @@ int p3_load_reads_device(p3_ctx* c, const void* d_bases, const void* d_offsets, 
   return set_reads_common(c, n_reads, total_bases, min_len);
 }
 
+/* ---- multi-rank protocol ------------------------------------------------------------------------------------ */
+int p3_mr_config(p3_ctx* c, uint32_t rank, uint32_t n_ranks) {
+  if (!c) return P3_EBADARG;
+  if (n_ranks == 0 || n_ranks > P3_MAX_RANKS || (P3_NB % n_ranks) != 0 || rank >= n_ranks)
+    return fail(c, P3_EBADARG, "n_ranks must divide %u and be <= %d (got rank %u of %u)", P3_NB, P3_MAX_RANKS, rank, n_ranks);
+  c->rank = rank;
+  c->n_ranks = n_ranks;
+  c->counted = c->bloomed = false;
+  c->mr_partitioned = false;
+  return P3_OK;
+}
+
+int p3_mr_count_partition(p3_ctx* c) {
+  if (!c) return P3_EBADARG;
+  if (!c->have_reads) return fail(c, P3_ESTATE, "no reads loaded");
+  if (!part_applicable(c)) return fail(c, P3_ECAPACITY, "input too large for the partitioned count (multi-rank needs it)");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if ((rc = do_pack(c))) return rc;
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  if ((rc = part_local(c))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->mr_partitioned = true;
+  c->counted = false;
+  return P3_OK;
+}
+
+int p3_mr_count_send_layout(p3_ctx* c, p3_mr_send_layout* out) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->mr_partitioned) return fail(c, P3_ESTATE, "p3_mr_count_partition first");
+  HIPCHK(c, hipSetDevice(c->device));
+  const u32 rows = P3_NB / c->n_ranks;
+  out->d_part = c->part.p;
+  out->d_ghist = c->ghist.p;
+  out->d_segoff = c->seg_off.p;
+  out->rows_per_rank = rows;
+  out->row_u32 = P3_NWG;
+  for (u32 d = 0; d < c->n_ranks; d++) {
+    u32 v = 0;
+    HIPCHK(c, hipMemcpy(&v, (const u32*)c->seg_off.p + (size_t)d * rows * P3_NWG, 4, hipMemcpyDeviceToHost));
+    out->rec_off[d] = v;
+  }
+  u64 tot[3];
+  HIPCHK(c, hipMemcpy(tot, (const u64*)c->dstats.p + 5, sizeof tot, hipMemcpyDeviceToHost));
+  out->rec_off[c->n_ranks] = tot[1];
+  c->cstats.n_windows = tot[0];
+  return P3_OK;
+}
+
+int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpart, void** d_rghist, void** d_rsegoff) {
+  if (!c || !recv_records || !d_rpart || !d_rghist || !d_rsegoff) return P3_EBADARG;
+  if (!c->mr_partitioned) return fail(c, P3_ESTATE, "p3_mr_count_partition first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  const u32 rows = P3_NB / c->n_ranks;
+  u64 roff[P3_MAX_RANKS + 1];
+  roff[0] = 0;
+  for (u32 s = 0; s < c->n_ranks; s++) {
+    if (recv_records[s] % 16) return fail(c, P3_ECOMM, "blob from rank %u is not a multiple of 16 records", s);
+    roff[s + 1] = roff[s] + recv_records[s];
+  }
+  if (roff[c->n_ranks] >= (1ull << 32)) return fail(c, P3_ECAPACITY, "received records exceed 32-bit indexing");
+  if ((rc = ensure(c, c->rx_part_buf, (roff[c->n_ranks] + 16) * 4))) return rc;
+  if ((rc = ensure(c, c->rx_ghist_buf, (size_t)c->n_ranks * rows * P3_NWG * 4))) return rc;
+  if ((rc = ensure(c, c->rx_segoff_buf, (size_t)c->n_ranks * rows * P3_NWG * 4))) return rc;
+  if ((rc = ensure(c, c->rx_roff, 8 * (P3_MAX_RANKS + 1)))) return rc;
+  HIPCHK(c, hipMemcpy(c->rx_roff.p, roff, 8 * (c->n_ranks + 1), hipMemcpyHostToDevice));
+  c->rx_part = c->rx_part_buf.p;
+  c->rx_ghist = c->rx_ghist_buf.p;
+  c->rx_segoff = c->rx_segoff_buf.p;
+  c->rx_records = roff[c->n_ranks];
+  *d_rpart = c->rx_part;
+  *d_rghist = c->rx_ghist;
+  *d_rsegoff = c->rx_segoff;
+  return P3_OK;
+}
+
+int p3_mr_initial_sbits(p3_ctx* c, uint32_t* sbits) {
+  if (!c || !sbits) return P3_EBADARG;
+  *sbits = initial_sbits(c->n_words * 32 * (u64)c->n_ranks);
+  return P3_OK;
+}
+
+int p3_mr_count_owned(p3_ctx* c, uint32_t sbits, int* overflowed, uint64_t* max_solid_sb) {
+  if (!c || !overflowed || !max_solid_sb) return P3_EBADARG;
+  if (!c->mr_partitioned || !c->rx_part) return fail(c, P3_ESTATE, "receive buffers not set up");
+  if (sbits < 1 || sbits > 5) return fail(c, P3_EBADARG, "sbits must be in [1,5]");
+  HIPCHK(c, hipSetDevice(c->device));
+  bool ovf = false;
+  u64 n_windows_local = c->cstats.n_windows;
+  int rc = count_owned(c, sbits, &ovf, max_solid_sb);
+  c->cstats.n_windows = n_windows_local;
+  *overflowed = ovf ? 1 : 0;
+  return rc;
+}
+
+uint32_t p3_rs_log2_for(uint64_t max_solid_sb) { return rs_log2_for(max_solid_sb); }
+
+int p3_mr_solid_build(p3_ctx* c, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes, uint64_t* owned_bytes,
+                      uint64_t* total_bytes) {
+  if (!c || !d_solid || !owned_offset_bytes || !owned_bytes || !total_bytes) return P3_EBADARG;
+  if (rs_log2 < 6 || rs_log2 > 15) return fail(c, P3_EBADARG, "rs_log2 out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = solid_build(c, rs_log2);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const u64 nsb_owned = (u64)(P3_NB / c->n_ranks) << c->sbits;
+  *d_solid = c->solid.p;
+  *owned_bytes = (nsb_owned << rs_log2) * 4;
+  *owned_offset_bytes = c->rank * *owned_bytes;
+  *total_bytes = *owned_bytes * c->n_ranks;
+  HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+  return P3_OK;
+}
+
+int p3_mr_bloom_buffer(p3_ctx* c, void** d_words, uint64_t* n_words_padded) {
+  if (!c || !d_words || !n_words_padded) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "no Bloom filter yet");
+  const u64 bwords = (c->m + 63) / 64;
+  *d_words = c->bloom.p;
+  *n_words_padded = (bwords + c->n_ranks - 1) / c->n_ranks * c->n_ranks;
+  return P3_OK;
+}
+
+int p3_mr_or_reduce(p3_ctx* c, void* d_dst, const void* d_src, uint64_t n_words, uint32_t n_src, uint64_t stride) {
+  if (!c || !d_dst || !d_src) return P3_EBADARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  LAUNCH(c, "k_or_reduce", k_or_reduce, grid_for(n_words), 256, (u64*)d_dst, (const u64*)d_src, n_words, n_src, stride);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return P3_OK;
+}
+
+int p3_mr_alloc_scratch(p3_ctx* c, uint64_t bytes, void** d_ptr) {
+  if (!c || !d_ptr) return P3_EBADARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->or_tmp, bytes);
+  if (rc) return rc;
+  *d_ptr = c->or_tmp.p;
+  return P3_OK;
+}
+
 int p3_count_short(p3_ctx* c) {
   if (!c) return P3_EBADARG;
   if (!c->have_reads) return fail(c, P3_ESTATE, "p3_count_short before p3_load_reads");
+  if (c->n_ranks != 1) return fail(c, P3_ECOMM, "context is configured for %u ranks: use the p3_mr_* protocol", c->n_ranks);
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));

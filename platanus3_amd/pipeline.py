@@ -2,10 +2,17 @@
 
     CountShortKmer(21)  ->  MakeBF<bitset<2k>>(reads, shortk_database, m, H, k, &seeds)
 
-`Pipeline` owns one C-ABI context (one HIP device).  With world > 1 it is one rank of a read-sharded
-job (see DESIGN.md "Multi-GPU"); the exchange steps use torch.distributed (RCCL on GPUs, gloo in the
-CPU tests) on buffers the C ABI hands out as plain device pointers.
+`Pipeline` owns one C-ABI context (one HIP device).  With world > 1 it is one rank of a read-sharded job:
+the compute stays behind the C ABI (p3_mr_* entry points) and this module only moves bytes between ranks
+with torch.distributed (RCCL on GPUs; the CPU tests drive the same orchestration over gloo with a stand-in
+backend).  Exchanges:
+
+  count   all-to-all of the bucket-partitioned canonical 21-mers to the bucket owners
+  gate    all-gather of the owners' solid-key regions (every rank then gates its own reads locally)
+  Bloom   OR-merge of the ranks' partial bit vectors: all-to-all of word chunks, local OR, all-gather
 """
+import numpy as np
+
 from . import capi
 
 # kernel name -> stage whose ALGORITHMIC bytes (SURVEY.md section 8d) it is credited with
@@ -16,27 +23,195 @@ STAGE_OF = {
     "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_bloom_insert": "bloom",
     "k_pos_hist": "bloom", "k_pos_scatter": "bloom", "k_bloom_slices": "bloom",
     "k_gate_direct": "bloom", "k_gate_regions": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
+    "k_or_reduce": "bloom",
 }
 
 
-class Pipeline:
-    def __init__(self, device=0, rank=0, world=1):
-        self.rank, self.world = rank, world
-        if world != 1:
-            raise NotImplementedError("multi-rank sharding is not wired up yet")
+class _DevMem:
+    """Zero-copy view of library-owned device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class HipBackend:
+    """The product backend: every method is a thin call into the C ABI; tensors are views of device memory."""
+
+    def __init__(self, device):
+        import torch
+        self.torch = torch
+        self.device = device
         self.ctx = capi.Context(device)
+
+    def bytes_tensor(self, ptr, nbytes):
+        if nbytes == 0:
+            return self.torch.empty(0, dtype=self.torch.uint8, device="cuda:%d" % self.device)
+        return self.torch.as_tensor(_DevMem(ptr, nbytes), device="cuda:%d" % self.device)
+
+    def tensor(self, ptr, count, dtype):
+        t = self.bytes_tensor(ptr, count * self.torch.empty(0, dtype=dtype).element_size())
+        return t.view(dtype)
+
+    def scalar_device(self):
+        return "cuda:%d" % self.device
+
+    # -- protocol steps -----------------------------------------------------------------------------------
+    def mr_config(self, rank, world):
+        self.ctx.mr_config(rank, world)
 
     def load_reads(self, bases, offsets, min_len):
         self.ctx.load_reads(bases, offsets, min_len)
 
-    def run_pass(self, k, m, H):
-        self.ctx.run_pass(k, m, H)
+    def mr_count_partition(self):
+        self.ctx.mr_count_partition()
+
+    def mr_send_layout(self):
+        lay = self.ctx.mr_count_send_layout()
+        t = self.torch
+        n_desc = 1024 * lay["row_u32"]
+        return dict(part=self.tensor(lay["d_part"], lay["rec_off"][-1], t.int32),
+                    ghist=self.tensor(lay["d_ghist"], n_desc, t.int32),
+                    segoff=self.tensor(lay["d_segoff"], n_desc, t.int32),
+                    rec_off=lay["rec_off"], rows=lay["rows"], row_u32=lay["row_u32"])
+
+    def mr_recv_alloc(self, recv_records, rows, row_u32, world):
+        a, b, c = self.ctx.mr_count_recv_alloc(recv_records)
+        t = self.torch
+        n_desc = world * rows * row_u32
+        return (self.tensor(a, int(sum(recv_records)), t.int32), self.tensor(b, n_desc, t.int32),
+                self.tensor(c, n_desc, t.int32))
+
+    def mr_initial_sbits(self):
+        return self.ctx.mr_initial_sbits()
+
+    def mr_count_owned(self, sbits):
+        return self.ctx.mr_count_owned(sbits)
+
+    def rs_log2_for(self, max_solid):
+        return self.ctx.rs_log2_for(max_solid)
+
+    def mr_solid_build(self, rs_log2):
+        p, off, own, tot = self.ctx.mr_solid_build(rs_log2)
+        return self.bytes_tensor(p, tot), off, own
+
+    def make_bloom(self, k, m, H):
+        self.ctx.make_bloom(k, m, H)
+
+    def mr_bloom_buffer(self):
+        self._bloom_ptr, n = self.ctx.mr_bloom_buffer()
+        return self.tensor(self._bloom_ptr, n, self.torch.int64)
+
+    def mr_scratch(self, n_words):
+        self._scratch_ptr = self.ctx.mr_alloc_scratch(n_words * 8)
+        return self.tensor(self._scratch_ptr, n_words, self.torch.int64)
+
+    def mr_or_reduce(self, dst_word, n_words, n_src, stride_words):
+        """bloom[dst_word + i] = OR_s scratch[s*stride_words + i]"""
+        self.ctx.mr_or_reduce(self._bloom_ptr + dst_word * 8, self._scratch_ptr, n_words, n_src, stride_words)
+
+
+class Pipeline:
+    def __init__(self, device=0, rank=0, world=1, backend=None, group=None, force_protocol=False):
+        self.rank, self.world, self.group = rank, world, group
+        self.be = backend if backend is not None else HipBackend(device)
+        self.ctx = getattr(self.be, "ctx", None)
+        self.protocol = world > 1 or force_protocol
+        if self.protocol:
+            self.be.mr_config(rank, world)
+        self.timing = {}
+
+    def load_reads(self, bases, offsets, min_len):
+        self.be.load_reads(bases, offsets, min_len)
 
     def synchronize(self):
-        pass  # every C-ABI pass call returns with its stream drained
+        pass  # every C-ABI call returns with its stream drained
 
+    # ---- the pass ---------------------------------------------------------------------------------------
+    def run_pass(self, k, m, H):
+        if not self.protocol:
+            self.ctx.run_pass(k, m, H)
+            return
+        import torch
+        import torch.distributed as dist
+        be, W, g = self.be, self.world, self.group
+        dev = be.scalar_device()
+
+        def allreduce_max(v):
+            t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+            if W > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+            return int(t.item())
+
+        # -- count: local partition, then blobs + descriptors to the bucket owners -------------------------
+        be.mr_count_partition()
+        lay = be.mr_send_layout()
+        rec_off, rows, row_u32 = lay["rec_off"], lay["rows"], lay["row_u32"]
+        send_counts = [rec_off[d + 1] - rec_off[d] for d in range(W)]
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rcnt = torch.empty_like(sc)
+        if W > 1:
+            dist.all_to_all_single(rcnt, sc, group=g)
+        else:
+            rcnt.copy_(sc)
+        recv_counts = [int(x) for x in rcnt.tolist()]
+        rpart, rghist, rsegoff = be.mr_recv_alloc(recv_counts, rows, row_u32, W)
+        desc = rows * row_u32
+        if W > 1:
+            dist.all_to_all_single(rpart, lay["part"][rec_off[0]:rec_off[W]], output_split_sizes=recv_counts,
+                                   input_split_sizes=send_counts, group=g)
+            dist.all_to_all_single(rghist, lay["ghist"], group=g)
+            dist.all_to_all_single(rsegoff, lay["segoff"], group=g)
+        else:
+            rpart.copy_(lay["part"][rec_off[0]:rec_off[1]])
+            rghist.copy_(lay["ghist"][:desc])
+            rsegoff.copy_(lay["segoff"][:desc])
+        self._sync(dev)
+        # -- owners count; the sub-bucket split grows in lockstep if any LDS table overflowed ---------------
+        sbits = allreduce_max(be.mr_initial_sbits())
+        while True:
+            ovf, max_solid = be.mr_count_owned(sbits)
+            if not allreduce_max(ovf):
+                break
+            sbits += 1
+            if sbits > 5:
+                raise capi.P3Error(3, "LDS count tables overflow at every sub-bucket split")
+        rs_log2 = be.rs_log2_for(allreduce_max(max_solid))
+        # -- gate: all-gather the owners' solid regions ------------------------------------------------------
+        solid, off, own = be.mr_solid_build(rs_log2)
+        if W > 1:
+            mine = solid[off:off + own].clone()
+            dist.all_gather_into_tensor(solid, mine, group=g)
+            self._sync(dev)
+        # -- Bloom: rank-local partial vector, then OR-merge ---------------------------------------------------
+        be.make_bloom(k, m, H)
+        if W > 1:
+            words = be.mr_bloom_buffer()
+            n = words.numel()
+            chunk = n // W
+            scratch = be.mr_scratch(n)
+            dist.all_to_all_single(scratch, words, group=g)
+            self._sync(dev)
+            be.mr_or_reduce(self.rank * chunk, chunk, W, chunk)
+            mine = words[self.rank * chunk:(self.rank + 1) * chunk].clone()
+            dist.all_gather_into_tensor(words, mine, group=g)
+            self._sync(dev)
+
+    def _sync(self, dev):
+        if str(dev).startswith("cuda"):
+            import torch
+            torch.cuda.synchronize()
+
+    # ---- results ------------------------------------------------------------------------------------------
     def global_distinct(self):
-        return self.ctx.count_stats()["n_distinct"]
+        n = self.ctx.count_stats()["n_distinct"]
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor([n], dtype=torch.int64, device=self.be.scalar_device())
+            dist.all_reduce(t, group=self.group)
+            n = int(t.item())
+        return n
 
     @staticmethod
     def stage_alg_bytes(L, D, R, m):

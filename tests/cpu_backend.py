@@ -1,0 +1,170 @@
+"""CPU stand-in for platanus3_amd.pipeline.HipBackend, used ONLY by the multi-rank orchestration tests.
+
+It speaks the same step protocol (partition -> exchange layout -> owners count -> solid regions -> rank-local
+Bloom -> OR merge) on CPU torch tensors, with numpy + the oracle doing the arithmetic, so that
+`Pipeline.run_pass` (the code that moves bytes between ranks) can be exercised over gloo without a GPU.
+The buffer FORMATS match the HIP library where the orchestration depends on them (bucket id = top 10 bits of
+the bijective 42-bit mix, 4-byte records, [1024][256] descriptor tables, 16-record padding, contiguous
+per-owner ranges); the solid table is opaque to the orchestration and uses its own simple encoding here.
+"""
+import numpy as np
+import torch
+
+NB, NWG = 1024, 256
+MIX_C = np.uint64(0x1E3779B97F5)
+M42 = np.uint64((1 << 42) - 1)
+
+
+def _modinv64(a):
+    x = int(a)
+    for _ in range(6):
+        x = (x * (2 - int(a) * x)) & ((1 << 64) - 1)
+    return x
+
+
+MIX_CINV = np.uint64(_modinv64(MIX_C) & ((1 << 42) - 1))
+
+
+def mix42(x):
+    x = x ^ (x >> np.uint64(21))
+    return (x * MIX_C) & M42
+
+
+def unmix42(g):
+    x = (g * MIX_CINV) & M42
+    return x ^ (x >> np.uint64(21))
+
+
+class CpuBackend:
+    def __init__(self, oracle):
+        self.o = oracle
+        self.timing = {}
+
+    def scalar_device(self):
+        return "cpu"
+
+    def mr_config(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def load_reads(self, bases, offsets, min_len):
+        self.reads = (np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(offsets, np.uint64))
+        self.min_len = min_len
+
+    # -- count ------------------------------------------------------------------------------------------------
+    def mr_count_partition(self):
+        keys = self.o.list_canon21(self.reads, min_len=self.min_len)
+        g = mix42(keys)
+        pb = (g >> np.uint64(32)).astype(np.int64)
+        order = np.argsort(pb, kind="stable")
+        rec = (g & np.uint64(0xffffffff)).astype(np.uint32)[order]
+        cnt = np.bincount(pb, minlength=NB).astype(np.int64)
+        ghist = np.zeros((NB, NWG), np.uint32)
+        segoff = np.zeros((NB, NWG), np.uint32)
+        ghist[:, 0] = cnt          # everything in workgroup column 0
+        padded = (cnt + 15) // 16 * 16
+        base = np.concatenate([[0], np.cumsum(padded)])
+        part = np.full(int(base[-1]), 0xdeadbeef, np.uint32)  # holes hold garbage, like the real buffer
+        src = np.concatenate([[0], np.cumsum(cnt)])
+        for b in range(NB):
+            part[base[b]:base[b] + cnt[b]] = rec[src[b]:src[b + 1]]
+            segoff[b, :] = base[b] + padded[b]   # empty segments sit at the end of the bucket ...
+            segoff[b, 0] = base[b]               # ... except column 0, which holds the data
+        self.part, self.ghist, self.segoff, self.base = part, ghist, segoff, base
+        self.n_windows = int(keys.size)
+
+    def mr_send_layout(self):
+        rows = NB // self.world
+        rec_off = [int(self.base[d * rows]) for d in range(self.world)] + [int(self.base[-1])]
+        return dict(part=torch.from_numpy(self.part.view(np.int32)), ghist=torch.from_numpy(self.ghist.reshape(-1).view(np.int32)),
+                    segoff=torch.from_numpy(self.segoff.reshape(-1).view(np.int32)), rec_off=rec_off, rows=rows, row_u32=NWG)
+
+    def mr_recv_alloc(self, recv_records, rows, row_u32, world):
+        self.recv_records = [int(x) for x in recv_records]
+        self.rpart = np.zeros(max(1, sum(self.recv_records)), np.uint32)
+        self.rghist = np.zeros(world * rows * row_u32, np.uint32)
+        self.rsegoff = np.zeros(world * rows * row_u32, np.uint32)
+        return (torch.from_numpy(self.rpart.view(np.int32))[:sum(self.recv_records)],
+                torch.from_numpy(self.rghist.view(np.int32)), torch.from_numpy(self.rsegoff.view(np.int32)))
+
+    def mr_initial_sbits(self):
+        return 1
+
+    def mr_count_owned(self, sbits):
+        W = self.world
+        rows = NB // W
+        gh = self.rghist.reshape(W, rows, NWG)
+        so = self.rsegoff.reshape(W, rows, NWG)
+        roff = np.concatenate([[0], np.cumsum(self.recv_records)])
+        gs = []
+        for s in range(W):
+            sbase = int(so[s, 0, 0])
+            for r in range(rows):
+                for wg in np.nonzero(gh[s, r])[0]:
+                    a = int(roff[s]) + int(so[s, r, wg]) - sbase
+                    recs = self.rpart[a:a + int(gh[s, r, wg])].astype(np.uint64)
+                    gs.append((np.uint64(self.rank * rows + r) << np.uint64(32)) | recs)
+        g = np.concatenate(gs) if gs else np.zeros(0, np.uint64)
+        ug, cnt = np.unique(g, return_counts=True)
+        keys = unmix42(ug)
+        order = np.argsort(keys)
+        self.shard_keys, self.shard_counts = keys[order], cnt[order].astype(np.uint64)
+        self.owned_g_solid = ug[cnt >= 2]
+        self.sbits = sbits
+        sb = (self.owned_g_solid >> np.uint64(32 - sbits)).astype(np.int64)
+        max_solid = int(np.bincount(sb).max()) if sb.size else 0
+        return 0, max_solid
+
+    def rs_log2_for(self, max_solid):
+        want = max_solid + (max_solid * 3) // 5 + 1
+        r = 6
+        while (1 << r) < want:
+            r += 1
+        return r
+
+    def mr_solid_build(self, rs_log2):
+        W, sbits = self.world, self.sbits
+        nsb_all = NB << sbits
+        nsb_owned = nsb_all // W
+        RS = 1 << rs_log2
+        if not hasattr(self, "solid") or self.solid.size != nsb_all * RS:
+            self.solid = np.zeros(nsb_all * RS, np.uint32)
+        table = self.solid.reshape(nsb_all, RS)
+        first = self.rank * nsb_owned
+        table[first:first + nsb_owned] = 0xffffffff
+        sb = (self.owned_g_solid >> np.uint64(32 - sbits)).astype(np.int64)
+        rem = (self.owned_g_solid & np.uint64((1 << (32 - sbits)) - 1)).astype(np.uint32)
+        for s in np.unique(sb):
+            r = np.sort(rem[sb == s])   # opaque encoding: sorted remainders, padded with EMPTY
+            table[s, :r.size] = r
+        self.rs_log2 = rs_log2
+        own_bytes = nsb_owned * RS * 4
+        return torch.from_numpy(self.solid.view(np.uint8)), self.rank * own_bytes, own_bytes
+
+    # -- Bloom ------------------------------------------------------------------------------------------------
+    def make_bloom(self, k, m, H):
+        sbits, RS = self.sbits, 1 << self.rs_log2
+        table = self.solid.reshape(NB << sbits, RS)
+        sb_idx, slot = np.nonzero(table != 0xffffffff)
+        g = (sb_idx.astype(np.uint64) << np.uint64(32 - sbits)) | table[sb_idx, slot].astype(np.uint64)
+        solid_keys = np.sort(unmix42(g))
+        words, seeds, _, _ = self.o.make_bf(self.reads, solid_keys, np.full(solid_keys.size, 2, np.uint64), k, m, H,
+                                            min_len=self.min_len)
+        n = (words.size + self.world - 1) // self.world * self.world
+        self.bloom = np.zeros(n, np.uint64)
+        self.bloom[:words.size] = words
+        self.n_bloom_words = words.size
+        self.seeds = seeds
+
+    def mr_bloom_buffer(self):
+        return torch.from_numpy(self.bloom.view(np.int64))
+
+    def mr_scratch(self, n_words):
+        self.scratch = np.zeros(n_words, np.uint64)
+        return torch.from_numpy(self.scratch.view(np.int64))
+
+    def mr_or_reduce(self, dst_word, n_words, n_src, stride_words):
+        d0 = dst_word
+        acc = np.zeros(n_words, np.uint64)
+        for s in range(n_src):
+            acc |= self.scratch[s * stride_words:s * stride_words + n_words]
+        self.bloom[d0:d0 + n_words] = acc

@@ -179,3 +179,24 @@ def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
             assert c.get_info("ksbits") > 0
     finally:
         c.close()
+
+
+def test_protocol_single_rank(oracle):
+    """The multi-rank protocol (partition -> owners count -> solid regions -> rank-local Bloom) driven with
+    one rank and no process group: same results as the single-call pass."""
+    from platanus3_amd.pipeline import Pipeline
+    b, o = synth.reads(seed=31, total_reads=20000, read_len=150)
+    k = 31
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    pipe = Pipeline(device=0, rank=0, world=1, force_protocol=True)
+    pipe.load_reads(b, o, min_len=k)
+    pipe.run_pass(k, m, H)
+    c = pipe.ctx
+    keys, counts = c.export_counts()
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    c.k, c.m, c.H = k, m, H
+    assert np.array_equal(c.export_bloom(), ebloom)
+    assert [capi.decode_key(r, k) for r in c.export_seeds()] == eseeds
+    c.close()

@@ -1,0 +1,76 @@
+"""CPU tier: the N>1 path.  world_size-2 and -4 gloo jobs run platanus3_amd.pipeline.Pipeline.run_pass -- the
+code that routes canonical 21-mers to their bucket owners, agrees on the split, all-gathers the solid regions
+and OR-merges the partial Bloom vectors -- with the CPU stand-in backend (tests/cpu_backend.py) in place of the
+HIP library.  The merged results must equal the single-rank oracle on the union of the reads, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, n_reads, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import platanus3_amd.synth as synth
+        from platanus3_amd.pipeline import Pipeline
+        from oracle.p3_oracle import Oracle
+        from cpu_backend import CpuBackend
+        o = Oracle()
+        per = n_reads // world
+        b, offs = synth.reads(seed=5, total_reads=n_reads, first_read=rank * per, n_reads=per, read_len=150)
+        m, H = o.estimate_bloom(n_reads * 150, k)
+        be = CpuBackend(o)
+        pipe = Pipeline(rank=rank, world=world, backend=be)
+        pipe.load_reads(b, offs, min_len=k)
+        pipe.run_pass(k, m, H)
+        np.savez(os.path.join(tmpdir, "rank%d.npz" % rank), keys=be.shard_keys, counts=be.shard_counts,
+                 bloom=be.bloom[:be.n_bloom_words], seeds=np.array(be.seeds, dtype="S") if be.seeds else np.zeros(0, "S1"))
+        # the pieces used to move across ranks must be owned-by-exactly-one-rank: a cheap global invariant
+        t = torch.tensor([be.shard_keys.size], dtype=torch.int64)
+        dist.all_reduce(t)
+        np.save(os.path.join(tmpdir, "total%d.npy" % rank), t.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 31), (4, 25), (2, 47)])
+def test_sharded_pass_equals_single_rank(tmp_path, oracle, world, k):
+    import platanus3_amd.synth as synth
+    n_reads = 1200
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, k, n_reads, str(tmp_path)), nprocs=world, join=True)
+    b, offs = synth.reads(seed=5, total_reads=n_reads, read_len=150)
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    ekeys, ecounts = oracle.count_short((b, offs), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, offs), ekeys, ecounts, k, m, H)
+    shards = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+    keys = np.concatenate([s["keys"] for s in shards])
+    counts = np.concatenate([s["counts"] for s in shards])
+    assert np.unique(keys).size == keys.size, "a key is owned by two ranks"
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], ekeys) and np.array_equal(counts[order], ecounts)
+    for s in shards:  # after the OR-merge + all-gather every rank holds the full vector
+        assert np.array_equal(s["bloom"], ebloom)
+    seeds = sorted(set(x.decode() for s in shards for x in s["seeds"]))
+    assert seeds == eseeds
+    assert int(np.load(os.path.join(tmp_path, "total0.npy"))[0]) == ekeys.size
