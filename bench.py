@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-protocol", action="store_true",
+                    help="run the multi-rank protocol code path even with one rank (testing)")
     return ap.parse_args()
 
 
@@ -100,7 +102,7 @@ def main():
     m, H = bloom_sizing(all_bases, k)
     n_k_total = total_reads * (L - k + 1)
 
-    pipe = Pipeline(device=local_rank, rank=rank, world=world)
+    pipe = Pipeline(device=local_rank, rank=rank, world=world, force_protocol=args.force_protocol)
     pipe.load_reads(b, o, min_len=k)  # H2D, untimed: inputs are resident in HBM when the clock starts
 
     def barrier():
@@ -128,10 +130,10 @@ def main():
     ms_per_step = dt * 1000.0 / args.steps
     value = n_k_total / (dt / args.steps)
 
+    D = pipe.global_distinct()  # collective: every rank takes part
     if rank == 0:
         stats = pipe.ctx.kernel_stats()
         cst = pipe.ctx.count_stats()
-        D = pipe.global_distinct()
         R = total_reads
         # ALGORITHMIC bytes: B_alg(read) = 2L + 16(L-20) + 16 D/R + m/(8R)
         b_alg_read = 2 * L + 16 * (L - 20) + 16.0 * D / R + m / (8.0 * R)

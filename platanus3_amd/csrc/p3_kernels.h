@@ -327,8 +327,14 @@ __global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, 
       seed_valid[r] = 0;
     }
   }
+  // one global atomic per BLOCK (a single word saturates near 90 atomics/us: one per wave cost ~0.18 ms here)
+  __shared__ u32 blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd((unsigned long long*)n_seed_reads, (unsigned long long)local);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(&blk, (u32)local);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicAdd((unsigned long long*)n_seed_reads, (unsigned long long)blk);
 }
 
 // ---- k_bloom_query: B2 -----------------------------------------------------------------------------------

@@ -128,9 +128,18 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
     n_valid += __shfl_down(n_valid, off, 64);
     n_pass += __shfl_down(n_pass, off, 64);
   }
+  // one pair of global atomics per block: reuse two histogram words (all histogram reads are done)
+  __syncthreads();
+  if (threadIdx.x < 2) hist[threadIdx.x] = 0;
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) {
-    if (n_valid) atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_valid);
-    if (n_pass) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_pass);
+    atomicAdd(&hist[0], (u32)n_valid);
+    atomicAdd(&hist[1], (u32)n_pass);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (hist[0]) atomicAdd((unsigned long long*)&stats[0], (unsigned long long)hist[0]);
+    if (hist[1]) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)hist[1]);
   }
 }
 

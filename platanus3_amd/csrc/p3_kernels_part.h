@@ -87,71 +87,72 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __rest
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
 }
 
-// ---- k_part_scan: one workgroup, thread pb owns bucket pb ----------------------------------------------
-// seg_off[pb*NWG + wg] = first record index of segment (pb,wg); every segment starts on a multiple of 16
-// records (64 bytes).  totals[0] = valid windows, totals[1] = padded records, totals[2] = largest bucket
-__global__ void __launch_bounds__(P3_NB) k_part_scan(const u32* __restrict__ ghist, u32* __restrict__ seg_off,
-                                                     u32* __restrict__ bucket_count, u64* __restrict__ totals) {
-  __shared__ u32 padded[P3_NB];
-  __shared__ u32 base[P3_NB];
+// ---- k_part_scan_*: seg_off[pb*NWG + wg] = first record index of segment (pb,wg); every segment starts on a
+// multiple of 16 records (64 bytes).
+// Three small launches instead of one single-workgroup kernel (which spent ~80 us walking 1024 rows with one
+// load in flight per wave):  a) per-row wave scan on 64 workgroups, b) scan of the 1024 row totals,
+// c) add the bucket base.
+__global__ void __launch_bounds__(256) k_part_scan_rows(const u32* __restrict__ ghist, u32* __restrict__ seg_off,
+                                                        u32* __restrict__ bucket_count, u32* __restrict__ padded) {
   static_assert(P3_NWG == 256, "one wave scans one 256-entry row with 4 entries per lane");
-  const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n_waves = blockDim.x >> 6;
-  // pass 1: within-bucket exclusive offsets (coalesced 16-byte loads, wave scan)
-  for (u32 pb = wave; pb < P3_NB; pb += n_waves) {
-    const uint4 c = reinterpret_cast<const uint4*>(ghist + pb * P3_NWG)[lane];
-    const u32 p0 = (c.x + 15u) & ~15u, p1 = (c.y + 15u) & ~15u, p2 = (c.z + 15u) & ~15u, p3 = (c.w + 15u) & ~15u;
-    u32 incl = p0 + p1 + p2 + p3, exact = c.x + c.y + c.z + c.w;
-    for (int off = 1; off < 64; off <<= 1) {
-      const u32 t = __shfl_up(incl, off, 64);
-      if ((int)lane >= off) incl += t;
-    }
-    for (int off = 32; off > 0; off >>= 1) exact += __shfl_down(exact, off, 64);
-    const u32 excl = incl - (p0 + p1 + p2 + p3);
-    reinterpret_cast<uint4*>(seg_off + pb * P3_NWG)[lane] = make_uint4(excl, excl + p0, excl + p0 + p1, excl + p0 + p1 + p2);
-    if (lane == 63) padded[pb] = incl;
-    if (lane == 0) bucket_count[pb] = exact;
+  const u32 lane = threadIdx.x & 63;
+  const u32 pb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pb >= P3_NB) return;
+  const uint4 c = reinterpret_cast<const uint4*>(ghist + pb * P3_NWG)[lane];
+  const u32 p0 = (c.x + 15u) & ~15u, p1 = (c.y + 15u) & ~15u, p2 = (c.z + 15u) & ~15u, p3 = (c.w + 15u) & ~15u;
+  u32 incl = p0 + p1 + p2 + p3, exact = c.x + c.y + c.z + c.w;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 t = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += t;
   }
-  __syncthreads();
-  // exclusive scan of the 1024 padded bucket sizes (Hillis-Steele in LDS)
-  const u32 t = threadIdx.x;
-  u32 v = padded[t];
-  base[t] = v;
+  for (int off = 32; off > 0; off >>= 1) exact += __shfl_down(exact, off, 64);
+  const u32 excl = incl - (p0 + p1 + p2 + p3);
+  reinterpret_cast<uint4*>(seg_off + pb * P3_NWG)[lane] = make_uint4(excl, excl + p0, excl + p0 + p1, excl + p0 + p1 + p2);
+  if (lane == 63) padded[pb] = incl;
+  if (lane == 0) bucket_count[pb] = exact;
+}
+
+// totals[0] = valid records, totals[1] = padded records, totals[2] = largest bucket; padded[] becomes base[]
+__global__ void __launch_bounds__(P3_NB) k_part_scan_base(u32* __restrict__ padded, const u32* __restrict__ bucket_count,
+                                                          u64* __restrict__ totals) {
+  __shared__ u32 buf[P3_NB];
+  const u32 t = threadIdx.x, lane = t & 63;
+  const u32 v = padded[t];
+  buf[t] = v;
   __syncthreads();
   for (u32 off = 1; off < P3_NB; off <<= 1) {
-    const u32 add = (t >= off) ? base[t - off] : 0;
+    const u32 add = (t >= off) ? buf[t - off] : 0;
     __syncthreads();
-    base[t] += add;
+    buf[t] += add;
     __syncthreads();
   }
-  const u32 incl_t = base[t];
-  __syncthreads();
-  base[t] = incl_t - v;
-  if (t == P3_NB - 1) totals[1] = incl_t;
-  {
-    u64 e = bucket_count[t];  // written by lane 0 of some wave of this block before the barrier above
-    u64 mx = e;
-    for (int off = 32; off > 0; off >>= 1) {
-      e += __shfl_down(e, off, 64);
-      const u64 o = __shfl_down(mx, off, 64);
-      mx = o > mx ? o : mx;
-    }
-    if (lane == 0) {
-      atomicAdd((unsigned long long*)&totals[0], (unsigned long long)e);
-      atomicMax((unsigned long long*)&totals[2], (unsigned long long)mx);
-    }
+  const u32 incl = buf[t];
+  padded[t] = incl - v;
+  if (t == P3_NB - 1) totals[1] = incl;
+  u64 e = bucket_count[t], mx = e;
+  for (int off = 32; off > 0; off >>= 1) {
+    e += __shfl_down(e, off, 64);
+    const u64 o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
   }
-  __syncthreads();
-  // pass 2: add the bucket base
-  for (u32 pb = wave; pb < P3_NB; pb += n_waves) {
-    uint4* row = reinterpret_cast<uint4*>(seg_off + pb * P3_NWG);
-    uint4 o = row[lane];
-    const u32 bb = base[pb];
-    o.x += bb;
-    o.y += bb;
-    o.z += bb;
-    o.w += bb;
-    row[lane] = o;
+  if (lane == 0) {
+    atomicAdd((unsigned long long*)&totals[0], (unsigned long long)e);
+    atomicMax((unsigned long long*)&totals[2], (unsigned long long)mx);
   }
+}
+
+__global__ void __launch_bounds__(256) k_part_scan_add(u32* __restrict__ seg_off, const u32* __restrict__ base) {
+  const u32 lane = threadIdx.x & 63;
+  const u32 pb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pb >= P3_NB) return;
+  uint4* row = reinterpret_cast<uint4*>(seg_off + pb * P3_NWG);
+  uint4 o = row[lane];
+  const u32 bb = base[pb];
+  o.x += bb;
+  o.y += bb;
+  o.z += bb;
+  o.w += bb;
+  row[lane] = o;
 }
 
 // ---- k_part_scatter ------------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ struct p3_ctx {
   int bloom_mode = 0;
   int tsk_log2_opt = 13;    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0;
-  DevBuf kpart, dkeys, ppart;
+  DevBuf kpart, dkeys, ppart, scan_tmp;
   // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
   u32 rank = 0, n_ranks = 1;
   DevBuf rx_roff, rx_part_buf, rx_ghist_buf, rx_segoff_buf, or_tmp;
@@ -278,6 +278,17 @@ int do_count_direct(p3_ctx* c) {
 // limits of the partitioned form: 32-bit record indices
 bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG * P3_NB < (1ull << 31); }
 
+// exact segment offsets from the (bucket, workgroup) histogram; totals -> st_totals[0..2]
+int do_scan(p3_ctx* c, u64* st_totals) {
+  int rc;
+  if ((rc = ensure(c, c->scan_tmp, (size_t)P3_NB * 4))) return rc;
+  LAUNCH(c, "k_part_scan", k_part_scan_rows, P3_NB / 4, 256, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
+         (u32*)c->bucket_count.p, (u32*)c->scan_tmp.p);
+  LAUNCH(c, "k_part_scan", k_part_scan_base, 1, P3_NB, (u32*)c->scan_tmp.p, (const u32*)c->bucket_count.p, st_totals);
+  LAUNCH(c, "k_part_scan", k_part_scan_add, P3_NB / 4, 256, (u32*)c->seg_off.p, (const u32*)c->scan_tmp.p);
+  return P3_OK;
+}
+
 // ---- partitioned count, in the three steps the multi-rank protocol interleaves with its exchanges ----------
 // (1) local partition of this rank's canonical 21-mers by bucket
 int part_local(p3_ctx* c) {
@@ -291,8 +302,7 @@ int part_local(p3_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
   LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
-  LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
-         (u32*)c->bucket_count.p, st + 5);  // totals at st[5..7]
+  if ((rc = do_scan(c, st + 5))) return rc;  // totals at st[5..7]
   const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
   LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
              (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
@@ -448,8 +458,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if ((rc = ensure(c, c->dkeys, (c->n_words * 32 + 1) * 8 * NW))) return rc;
     LAUNCH(c, "k_kmer_hist", (k_kmer_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
            (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, (u32*)c->ghist.p, (u32*)c->P.p, st + 8);
-    LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
-           (u32*)c->bucket_count.p, st + 12);  // totals at st[12..14]
+    if ((rc = do_scan(c, st + 12))) return rc;  // totals at st[12..14]
     const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
     LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
                (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->P.p, c->n_words, k,
@@ -485,8 +494,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if ((rc = ensure(c, c->ppart, (n_pos + 16ull * P3_NWG * P3_NB) * 4))) return rc;
         LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, h[0], k, mm, H,
                slice_log2, (u32*)c->ghist.p);
-        LAUNCH(c, "k_part_scan", k_part_scan, 1, P3_NB, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
-               (u32*)c->bucket_count.p, st + 12);
+        if ((rc = do_scan(c, st + 12))) return rc;
         LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
                    h[0], k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p);
         const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
@@ -511,7 +519,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     c->bloom_mode = 1;
   }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads), 256, c->d_offsets, c->n_reads, c->min_len, k,
+  LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
          (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 hb[3];
@@ -590,7 +598,7 @@ int p3_destroy(p3_ctx* c) {
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
                     &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart, &c->rx_roff, &c->rx_part_buf, &c->rx_ghist_buf, &c->rx_segoff_buf,
-                    &c->or_tmp};
+                    &c->or_tmp, &c->scan_tmp};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
