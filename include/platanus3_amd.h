@@ -60,6 +60,9 @@ int p3_set_profiling(p3_ctx* ctx, int on);
  *                 global-table kernels, 2 = force the partitioned kernels (error if they cannot be used)
  *   "ts_log2"     log2 of the LDS count-table slots per sub-bucket (<= 14); small values force the
  *                 overflow -> re-split -> direct fallback chain in tests
+ *   "gate_mode"   0 = auto (return path when the input fits), 1 = probe the solid-key regions once per window,
+ *                 2 = return path: partition records carry window positions and the count stage hands back the
+ *                 positions of the non-solid windows (no table probes)
  *   "bloom_mode"  0 = auto (dedup form when the input fits), 1 = direct (H probes per passing window),
  *                 2 = dedup (H probes per distinct passing k-mer; error if it cannot be used)
  *   "bloom_slices" 1 (default) = after dedup, probe positions are partitioned by bit-vector slice and OR-ed
@@ -142,17 +145,20 @@ int p3_reset_kernel_stats(p3_ctx* ctx);
  *     [all-to-all of per-destination record counts, then of the blobs and their descriptor rows]
  *   -> p3_mr_count_recv_alloc (before the data all-to-all) -> p3_mr_count_owned(sbits)
  *     [all-reduce MAX of `overflowed`: if set, every rank repeats with sbits+1; all-reduce MAX of max_solid_sb]
- *   -> p3_mr_solid_build(p3_rs_log2_for(max)) [all-gather of the owned byte range of d_solid]
+ *   -> gate_mode 2: p3_mr_singles_layout [all-to-all of the non-solid position lists back to their source
+ *        ranks] -> p3_mr_nonsolid_recv_alloc / p3_mr_solid_bits
+ *      gate_mode 1: p3_mr_solid_build(p3_rs_log2_for(max)) [all-gather of the owned byte range of d_solid]
  *   -> p3_make_bloom (rank-local) -> p3_mr_bloom_buffer [all-to-all of equal word chunks into scratch,
  *      p3_mr_or_reduce into the own chunk, all-gather] -> exports as in the single-rank case
  *      (p3_export_counts returns this rank's shard of the table; the global table is the disjoint union). */
 #define P3_MAX_RANKS 64
 typedef struct {
-  void* d_part;      /* uint32 records; the blob for rank d is records [rec_off[d], rec_off[d+1])          */
+  void* d_part;      /* rec_bytes-sized records; the blob for rank d is records [rec_off[d], rec_off[d+1])   */
   void* d_ghist;     /* [1024][row_u32] uint32 counts; rows [d*rows_per_rank, (d+1)*rows_per_rank) go to d   */
   void* d_segoff;    /* same shape: record offsets of the segments (relative to this rank's d_part)           */
   uint64_t rec_off[P3_MAX_RANKS + 1];
   uint32_t rows_per_rank, row_u32;
+  uint32_t rec_bytes; /* 4, or 8 when the records carry window positions (return-path gate) */
 } p3_mr_send_layout;
 int p3_mr_config(p3_ctx* ctx, uint32_t rank, uint32_t n_ranks); /* n_ranks must divide 1024 */
 int p3_mr_count_partition(p3_ctx* ctx);
@@ -167,6 +173,14 @@ int p3_mr_count_owned(p3_ctx* ctx, uint32_t sbits, int* overflowed, uint64_t* ma
 uint32_t p3_rs_log2_for(uint64_t max_solid_sb);
 int p3_mr_solid_build(p3_ctx* ctx, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes,
                       uint64_t* owned_bytes, uint64_t* total_bytes);
+/* Return-path gate (gate_mode 2, the default when the input fits): after p3_mr_count_owned the owner holds,
+ * per source rank s, the list of window positions (uint32, local to rank s) whose 21-mer occurs exactly once:
+ * counts[s] entries starting at element offsets[s] of *d_singles.  The host returns list s to rank s
+ * (all-to-all), concatenated into the buffer of p3_mr_nonsolid_recv_alloc; p3_mr_solid_bits then assembles the
+ * solid-window bitmap.  This replaces p3_mr_solid_build + the all-gather of regions (gate_mode 1). */
+int p3_mr_singles_layout(p3_ctx* ctx, void** d_singles, uint64_t* offsets, uint64_t* counts);
+int p3_mr_nonsolid_recv_alloc(p3_ctx* ctx, uint64_t total_positions, void** d_buf);
+int p3_mr_solid_bits(p3_ctx* ctx, uint64_t n_positions);
 int p3_mr_bloom_buffer(p3_ctx* ctx, void** d_words, uint64_t* n_words_padded /* multiple of n_ranks */);
 /* dst[i] = OR over s of src[s*stride_words + i] (uint64 words, device pointers) */
 int p3_mr_or_reduce(p3_ctx* ctx, void* d_dst, const void* d_src, uint64_t n_words, uint32_t n_src,

@@ -40,7 +40,8 @@ P3_MAX_RANKS = 64
 
 class MrSendLayout(C.Structure):
     _fields_ = [("d_part", C.c_void_p), ("d_ghist", C.c_void_p), ("d_segoff", C.c_void_p),
-                ("rec_off", C.c_uint64 * (P3_MAX_RANKS + 1)), ("rows_per_rank", C.c_uint32), ("row_u32", C.c_uint32)]
+                ("rec_off", C.c_uint64 * (P3_MAX_RANKS + 1)), ("rows_per_rank", C.c_uint32), ("row_u32", C.c_uint32),
+                ("rec_bytes", C.c_uint32)]
 
 
 _lib = None
@@ -91,6 +92,9 @@ def load(build=False):
     L.p3_rs_log2_for.restype = u32
     L.p3_rs_log2_for.argtypes = [u64]
     L.p3_mr_solid_build.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.p3_mr_singles_layout.argtypes = [vp, C.POINTER(vp), C.POINTER(u64), C.POINTER(u64)]
+    L.p3_mr_nonsolid_recv_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+    L.p3_mr_solid_bits.argtypes = [vp, u64]
     L.p3_mr_bloom_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.p3_mr_or_reduce.argtypes = [vp, vp, vp, u64, u32, u64]
     L.p3_mr_alloc_scratch.argtypes = [vp, u64, C.POINTER(vp)]
@@ -226,7 +230,8 @@ class Context:
         self._chk(self.L.p3_mr_count_send_layout(self.h, C.byref(lay)))
         n = self.n_ranks
         return dict(d_part=lay.d_part, d_ghist=lay.d_ghist, d_segoff=lay.d_segoff,
-                    rec_off=[int(lay.rec_off[i]) for i in range(n + 1)], rows=lay.rows_per_rank, row_u32=lay.row_u32)
+                    rec_off=[int(lay.rec_off[i]) for i in range(n + 1)], rows=lay.rows_per_rank, row_u32=lay.row_u32,
+                    rec_bytes=lay.rec_bytes)
 
     def mr_count_recv_alloc(self, recv_records):
         arr = (C.c_uint64 * len(recv_records))(*[int(x) for x in recv_records])
@@ -251,6 +256,21 @@ class Context:
         p, off, own, tot = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._chk(self.L.p3_mr_solid_build(self.h, rs_log2, C.byref(p), C.byref(off), C.byref(own), C.byref(tot)))
         return p.value, off.value, own.value, tot.value
+
+    def mr_singles_layout(self):
+        p = C.c_void_p()
+        offs = (C.c_uint64 * self.n_ranks)()
+        cnts = (C.c_uint64 * self.n_ranks)()
+        self._chk(self.L.p3_mr_singles_layout(self.h, C.byref(p), offs, cnts))
+        return p.value, [int(x) for x in offs], [int(x) for x in cnts]
+
+    def mr_nonsolid_recv_alloc(self, total):
+        p = C.c_void_p()
+        self._chk(self.L.p3_mr_nonsolid_recv_alloc(self.h, total, C.byref(p)))
+        return p.value
+
+    def mr_solid_bits(self, n_positions):
+        self._chk(self.L.p3_mr_solid_bits(self.h, n_positions))
 
     def mr_bloom_buffer(self):
         p, n = C.c_void_p(), C.c_uint64()

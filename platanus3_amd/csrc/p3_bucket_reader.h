@@ -14,7 +14,7 @@
 // Calls f(recs, active_mask) with batches of 4*(16/sizeof(REC)) records of bucket pb (bit i of the mask says
 // whether recs[i] is a real record).  ALL threads of the workgroup must call this (it
 // synchronises).  valid: LDS byte array of P3_VALID_CAP entries; sc2: two LDS u32 scratch words.
-template <typename REC, typename F>
+template <typename REC, u32 VCAP = P3_VALID_CAP, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
                                                 const u32* __restrict__ ghist, u32 pb, uint8_t* valid, u32* sc2,
                                                 F f) {
@@ -34,8 +34,8 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
   const u32 nch = (sc2[1] - start) >> 4;       // chunks in the bucket
   const u32 my_c0 = (my_off - start) >> 4;     // first chunk of my segment
   const u32 my_nc = (my_n + 15u) >> 4;         // chunks of my segment
-  for (u32 wb = 0; wb < nch; wb += P3_VALID_CAP) {
-    const u32 wn = (nch - wb) < P3_VALID_CAP ? (nch - wb) : P3_VALID_CAP;
+  for (u32 wb = 0; wb < nch; wb += VCAP) {
+    const u32 wn = (nch - wb) < VCAP ? (nch - wb) : VCAP;
     if (threadIdx.x < P3_NWG) {
       // chunks [my_c0, my_c0+my_nc) intersected with [wb, wb+wn)
       u32 lo = my_c0 > wb ? my_c0 : wb;

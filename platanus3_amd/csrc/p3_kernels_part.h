@@ -16,6 +16,8 @@
 // Quotienting: g is a bijection on [0,2^42), so (bucket, sub-bucket, remainder) identifies the key and
 // a partition record is 4 bytes instead of 8.
 #pragma once
+#include <type_traits>
+
 #include "p3_kernels.h"
 
 #define P3_PBITS 10
@@ -276,16 +278,35 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __r
 // offset roff[s] of `part`), each with its own [rows][NWG] descriptor tables stacked in seg_off / ghist; a
 // source's offsets are relative to its own buffer, so they are rebased by its first descriptor.  With one
 // rank: n_src = 1, rows = NB, roff[0] = 0, first_pb = 0 and `part` is the local partition itself.
-__global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+// POS = true: records are 8 bytes (low 32 bits of g | window position << 32).  The position of the instance
+// that FIRST inserts a key is kept (tpos, global, one word per table slot; tsrc = its source rank when there
+// are several); after counting, the keys with count 1 hand their single instance's position to the per-source
+// "non-solid" lists -- the return path that replaces 130 M random solid-table probes in the gate by
+// ~12 M list entries (the count threshold is 2, so non-solid == exactly one instance).
+//   sing_cursor[s] (zeroed by the host) = entries emitted for source s; list s starts at singles[roff[s]].
+#define P3_VCAP_POS 4096u
+#define P3_WQ_CAP_POS 192u
+template <bool POS>
+__global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
+                                                     const u32* __restrict__ seg_off,
                                                      const u32* __restrict__ ghist, const u64* __restrict__ roff,
                                                      u32 n_src, u32 rows, u32 first_pb, u32 sbits, u32 ts_log2,
                                                      u64* __restrict__ out_keys, u32* __restrict__ out_counts,
-                                                     uint4* __restrict__ sb_info, u64* __restrict__ gstats) {
+                                                     uint4* __restrict__ sb_info, u64* __restrict__ gstats,
+                                                     u32* __restrict__ tpos, uint8_t* __restrict__ tsrc,
+                                                     u32* __restrict__ singles, u64* __restrict__ sing_cursor) {
+  typedef typename std::conditional<POS, u64, u32>::type REC;
+  constexpr u32 VCAP = POS ? P3_VCAP_POS : P3_VALID_CAP;
+  constexpr u32 QCAP = POS ? P3_WQ_CAP_POS : P3_WQ_CAP;
+  constexpr int NBATCH = POS ? 8 : 16;  // records per reader batch
+  constexpr int G = POS ? 2 : 4;        // records per lane between queue drains
   extern __shared__ __align__(16) u32 lds[];
   const u32 TS = 1u << ts_log2;
   u32* tkey = lds;
   u32* tcnt = lds + TS;
   u32* sc = lds + 2 * TS;  // scalars live behind the table so the dynamic region keeps its alignment
+  u32* s_sing = sc + 16;      // [64] singles per source (POS)
+  u32* s_singbase = sc + 80;  // [64]
 #define s_ndist sc[0]
 #define s_cur sc[1]
 #define s_base_lo sc[2]
@@ -304,6 +325,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
     s_max = 0;
     s_ovf = 0;
   }
+  if (threadIdx.x < 128) sc[16 + threadIdx.x] = 0;
   __syncthreads();
   const u32 sb = blockIdx.x;           // owned (local) sub-bucket index
   const u32 pb_local = sb >> sbits;
@@ -313,15 +335,25 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
   const u32 lane = threadIdx.x & 63;
   const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
-  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
-  auto slow_insert = [&](u32 rem, u32 slot) {
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 144);
+  const u64 tbase = (u64)sb * TS;  // this sub-bucket's window of tpos / tsrc
+  u32 cur_src = 0;
+  auto slow_insert = [&](REC item) {
+    const u32 rem = (u32)item & rem_mask;
+    u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       u32 old = tkey[slot];
       if (old == P3_EMPTY32) {
         if (__hip_atomic_load(&s_ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) break;
         old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
-        if (old == P3_EMPTY32) atomicAdd(&s_ndist, 1u);
+        if (old == P3_EMPTY32) {
+          atomicAdd(&s_ndist, 1u);
+          if constexpr (POS) {
+            tpos[tbase + slot] = (u32)((u64)item >> 32);
+            if (n_src > 1) tsrc[tbase + slot] = (uint8_t)cur_src;
+          }
+        }
       }
       if (old == P3_EMPTY32 || old == rem) {
         atomicAdd(&tcnt[slot], 1u);
@@ -335,47 +367,45 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
   // Probing is data dependent, so a per-record probe loop costs the LONGEST chain among the 64 lanes for
   // every record.  Instead: all lanes do the (uniform) home-slot check; misses go to a per-wave LDS queue
   // and are drained 64 at a time, one item per lane, so the divergent loop always runs with full lanes.
-  u32* wq = reinterpret_cast<u32*>(valid + P3_VALID_CAP) + (threadIdx.x >> 6) * P3_WQ_CAP;
+  REC* wq = reinterpret_cast<REC*>(valid + VCAP) + (threadIdx.x >> 6) * QCAP;
   u32 qn = 0;  // wave-uniform
   const unsigned long long lt_mask = (1ULL << lane) - 1;
   for (u32 src = 0; src < n_src; src++) {
-  const u32 row = src * rows + pb_local;
-  const u32* part_src = part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
-  bucket_for_each<u32>(part_src, seg_off, ghist, row, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
+    cur_src = src;
+    const u32 row = src * rows + pb_local;
+    const REC* part_src = part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
+    bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; g4++) {
-      u32 rem[4], slot[4], cur[4];
+      for (int g0 = 0; g0 < NBATCH; g0 += G) {
+        u32 rem[G], slot[G], cur[G];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int i = 4 * g4 + t;
-        rem[t] = r[i] & rem_mask;
-        slot[t] = (rem[t] * 0x9E3779B1u) >> (32 - ts_log2);
-        cur[t] = tkey[slot[t]];
-      }
+        for (int t = 0; t < G; t++) {
+          rem[t] = (u32)r[g0 + t] & rem_mask;
+          slot[t] = (rem[t] * 0x9E3779B1u) >> (32 - ts_log2);
+          cur[t] = tkey[slot[t]];
+        }
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const int i = 4 * g4 + t;
-        const bool mine = (act & (1u << i)) && ((r[i] >> rem_bits) == subsel);
-        const bool hit = mine && cur[t] == rem[t];
-        if (hit) atomicAdd(&tcnt[slot[t]], 1u);
-        const bool miss = mine && !hit;
-        const unsigned long long bal = __ballot(miss);
-        if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = rem[t];
-        qn += (u32)__popcll(bal);
+        for (int t = 0; t < G; t++) {
+          const int i = g0 + t;
+          const bool mine = (act & (1u << i)) && (((u32)r[i] >> rem_bits) == subsel);
+          const bool hit = mine && cur[t] == rem[t];
+          if (hit) atomicAdd(&tcnt[slot[t]], 1u);
+          const bool miss = mine && !hit;
+          const unsigned long long bal = __ballot(miss);
+          if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = r[i];
+          qn += (u32)__popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        while (qn >= 64) {
+          qn -= 64;
+          slow_insert(wq[qn + lane]);
+        }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      while (qn >= 64) {
-        qn -= 64;
-        const u32 item = wq[qn + lane];
-        slow_insert(item, (item * 0x9E3779B1u) >> (32 - ts_log2));
-      }
-    }
-  });
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (lane < qn) {
-    const u32 item = wq[lane];
-    slow_insert(item, (item * 0x9E3779B1u) >> (32 - ts_log2));
+    });
+    // the queue is emptied before the next source so that a first insertion is credited to the right rank
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < qn) slow_insert(wq[lane]);
+    qn = 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -403,6 +433,24 @@ __global__ void __launch_bounds__(1024) k_part_count(const u32* __restrict__ par
       out_counts[base + idx] = c;
       my_solid += (c >= 2);
       my_max = c > my_max ? c : my_max;
+      if constexpr (POS)
+        if (c == 1) atomicAdd(&s_sing[(n_src > 1) ? tsrc[tbase + i] : 0u], 1u);
+    }
+  }
+  if constexpr (POS) {
+    __syncthreads();
+    if (threadIdx.x < n_src) {
+      const u32 n = s_sing[threadIdx.x];
+      s_singbase[threadIdx.x] = n ? (u32)atomicAdd((unsigned long long*)&sing_cursor[threadIdx.x], (unsigned long long)n) : 0u;
+      s_sing[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+      if (tkey[i] != P3_EMPTY32 && tcnt[i] == 1) {
+        const u32 src = (n_src > 1) ? tsrc[tbase + i] : 0u;
+        const u32 idx = atomicAdd(&s_sing[src], 1u);
+        singles[roff[src] + s_singbase[src] + idx] = tpos[tbase + i];
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {

@@ -16,6 +16,7 @@
 #include "p3_kernels.h"
 #include "p3_kernels_part.h"
 #include "p3_kernels_bloom.h"
+#include "p3_kernels_retgate.h"
 
 namespace {
 
@@ -74,6 +75,13 @@ struct p3_ctx {
   void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
   u64 rx_records = 0;
   bool mr_partitioned = false;
+  // coverage gate: 1 = probe the solid-key regions per window, 2 = return path (non-solid positions come back
+  // from the count stage and S is assembled without any table probe)
+  int gate_mode_opt = 0, gate_mode = 1;
+  bool part_pos = false;  // the current partition carries positions (8-byte records)
+  DevBuf part8, tpos, tsrc, singles, sing_cursor, ns_recv, ns_part;
+  u64 sing_count[P3_MAX_RANKS] = {0};
+  bool s_ready = false;
   int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
 
@@ -270,6 +278,8 @@ int do_count_direct(p3_ctx* c) {
   c->cstats.max_count = h[2];
   c->cstats.n_windows = h[3];
   c->count_mode = 1;
+  c->gate_mode = 1;
+  c->s_ready = false;
   c->ccounts_u32 = false;
   c->counted = true;
   return P3_OK;
@@ -291,21 +301,35 @@ int do_scan(p3_ctx* c, u64* st_totals) {
 
 // ---- partitioned count, in the three steps the multi-rank protocol interleaves with its exchanges ----------
 // (1) local partition of this rank's canonical 21-mers by bucket
-int part_local(p3_ctx* c) {
+bool retgate_applicable(const p3_ctx* c) { return part_applicable(c) && c->n_words * 32 <= (1ull << 30); }
+
+int part_local(p3_ctx* c, bool with_pos) {
   int rc;
   const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
   if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
-  if ((rc = ensure(c, c->part, max_records * 4))) return rc;
+  if (with_pos) {
+    if ((rc = ensure(c, c->part8, max_records * 8))) return rc;
+  } else {
+    if ((rc = ensure(c, c->part, max_records * 4))) return rc;
+  }
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
   LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
   if ((rc = do_scan(c, st + 5))) return rc;  // totals at st[5..7]
-  const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
-  LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
-             (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
+  if (with_pos) {
+    const size_t lds = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+    LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
+               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u64*)c->part8.p);
+  } else {
+    const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
+    LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
+               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
+  }
+  c->part_pos = with_pos;
+  c->s_ready = false;
   return P3_OK;
 }
 
@@ -322,10 +346,25 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
-  const size_t lds = ((size_t)2 << ts_log2) * 4 + 64 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
-  LAUNCH_LDS(c, "k_part_count", k_part_count, nsb, 1024, lds, (const u32*)c->rx_part, (const u32*)c->rx_segoff,
-             (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows, c->rank * rows, sbits, ts_log2,
-             (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st);
+  if (c->part_pos) {
+    if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 4))) return rc;
+    if (c->n_ranks > 1 && (rc = ensure(c, c->tsrc, (size_t)nsb << ts_log2))) return rc;
+    if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
+    if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
+    const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->rx_part,
+               (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+               c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+               (u32*)c->tpos.p, (uint8_t*)c->tsrc.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p);
+    HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)c->rx_part,
+               (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+               c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+               (u32*)nullptr, (uint8_t*)nullptr, (u32*)nullptr, (u64*)nullptr);
+  }
   u64 h[8];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -353,6 +392,37 @@ int solid_build(p3_ctx* c, u32 rs_log2) {
              (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, c->rank * nsb_owned, c->sbits, rs_log2,
              (u32*)c->solid.p);
   c->count_mode = 2;
+  c->gate_mode = 1;
+  c->counted = true;
+  return P3_OK;
+}
+
+// (3') return path: S from the list of non-solid window positions (no table probes)
+int solid_bits(p3_ctx* c, const u32* d_positions, u64 n_pos) {
+  int rc;
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  const u64 n_bits = c->n_words * 32;
+  u32 slice_log2 = 15;
+  while ((n_bits >> slice_log2) >= P3_NB) slice_log2++;
+  if (slice_log2 > 20) return fail(c, P3_ECAPACITY, "window bitmap too large for the return-path gate");
+  const u32 ns = (u32)((n_bits + ((1ull << slice_log2) - 1)) >> slice_log2);
+  if ((rc = ensure(c, c->S, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->ns_part, (n_pos + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 12, 0, 3 * 8, c->stream));
+  LAUNCH(c, "k_u32_hist", k_u32_hist, P3_NWG, P3_PART_THREADS, d_positions, n_pos, slice_log2, (u32*)c->ghist.p);
+  if ((rc = do_scan(c, st + 12))) return rc;
+  const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+  LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, n_pos, slice_log2,
+             (const u32*)c->seg_off.p, (u32*)c->ns_part.p);
+  const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
+  LAUNCH_LDS(c, "k_solid_slices", k_solid_slices, ns ? ns : 1, 1024, lds_bm, (const u32*)c->ns_part.p,
+             (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, (const u32*)c->endm.p, c->n_words,
+             (u32*)c->S.p);
+  c->s_ready = true;
+  c->gate_mode = 2;
+  c->count_mode = 2;
   c->counted = true;
   return P3_OK;
 }
@@ -375,7 +445,7 @@ int set_rx_local(p3_ctx* c) {
   int rc;
   if ((rc = ensure(c, c->rx_roff, 8 * 16))) return rc;
   HIPCHK(c, hipMemsetAsync(c->rx_roff.p, 0, 8 * 16, c->stream));
-  c->rx_part = c->part.p;
+  c->rx_part = c->part_pos ? c->part8.p : c->part.p;
   c->rx_ghist = c->ghist.p;
   c->rx_segoff = c->seg_off.p;
   c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
@@ -387,7 +457,9 @@ int set_rx_local(p3_ctx* c) {
 int do_count_part(p3_ctx* c, bool* overflowed) {
   int rc;
   *overflowed = false;
-  if ((rc = part_local(c))) return rc;
+  const bool with_pos = c->gate_mode_opt != 1 && retgate_applicable(c);
+  if (c->gate_mode_opt == 2 && !with_pos) return fail(c, P3_EBADARG, "return-path gate forced but input too large");
+  if ((rc = part_local(c, with_pos))) return rc;
   if ((rc = set_rx_local(c))) return rc;
   u64 max_solid = 0;
   for (u32 sbits = initial_sbits(c->n_words * 32);; sbits++) {
@@ -399,6 +471,7 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
     if ((rc = count_owned(c, sbits, &ovf, &max_solid))) return rc;
     if (!ovf) break;
   }
+  if (with_pos) return solid_bits(c, (const u32*)c->singles.p, c->sing_count[0]);
   return solid_build(c, rs_log2_for(max_solid));
 }
 
@@ -431,12 +504,15 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
   if ((rc = ensure(c, c->seed_valid, c->n_reads + 1))) return rc;
   u64* st = (u64*)c->dstats.p;
-  HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
+  const bool have_s = c->count_mode == 2 && c->gate_mode == 2 && c->s_ready;
+  if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  if (c->count_mode == 2) {
+  if (have_s) {
+    // S was assembled by the count stage's return path
+  } else if (c->count_mode == 2) {
     LAUNCH(c, "k_gate_regions", k_gate_regions, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
            (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p, c->sbits, c->rs_log2, (u32*)c->S.p);
   } else {
@@ -598,7 +674,8 @@ int p3_destroy(p3_ctx* c) {
   DevBuf* bufs[] = {&c->owned_bases, &c->owned_offsets, &c->fw, &c->rcw, &c->endm, &c->S, &c->P, &c->tkeys,
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
                     &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart, &c->rx_roff, &c->rx_part_buf, &c->rx_ghist_buf, &c->rx_segoff_buf,
-                    &c->or_tmp, &c->scan_tmp};
+                    &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
+                    &c->ns_part};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -621,6 +698,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   if (n == "count_mode") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "count_mode must be 0 (auto), 1 (direct) or 2 (partitioned)");
     c->count_mode_opt = (int)value;
+  } else if (n == "gate_mode") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "gate_mode must be 0 (auto), 1 (table probes) or 2 (return path)");
+    c->gate_mode_opt = (int)value;
   } else if (n == "bloom_mode") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "bloom_mode must be 0 (auto), 1 (direct) or 2 (dedup)");
     c->bloom_mode_opt = (int)value;
@@ -643,6 +723,8 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   const std::string n(name);
   if (n == "count_mode") *value = c->count_mode;
   else if (n == "bloom_mode") *value = c->bloom_mode;
+  else if (n == "gate_mode") *value = c->gate_mode;
+  else if (n == "nonsolid_windows") *value = (int64_t)c->sing_count[0];
   else if (n == "ksbits") *value = c->ksbits;
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
@@ -702,7 +784,8 @@ int p3_mr_count_partition(p3_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if ((rc = do_pack(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if ((rc = part_local(c))) return rc;
+  const bool with_pos = c->gate_mode_opt != 1 && retgate_applicable(c);
+  if ((rc = part_local(c, with_pos))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->mr_partitioned = true;
   c->counted = false;
@@ -714,7 +797,8 @@ int p3_mr_count_send_layout(p3_ctx* c, p3_mr_send_layout* out) {
   if (!c->mr_partitioned) return fail(c, P3_ESTATE, "p3_mr_count_partition first");
   HIPCHK(c, hipSetDevice(c->device));
   const u32 rows = P3_NB / c->n_ranks;
-  out->d_part = c->part.p;
+  out->d_part = c->part_pos ? c->part8.p : c->part.p;
+  out->rec_bytes = c->part_pos ? 8 : 4;
   out->d_ghist = c->ghist.p;
   out->d_segoff = c->seg_off.p;
   out->rows_per_rank = rows;
@@ -744,7 +828,7 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
     roff[s + 1] = roff[s] + recv_records[s];
   }
   if (roff[c->n_ranks] >= (1ull << 32)) return fail(c, P3_ECAPACITY, "received records exceed 32-bit indexing");
-  if ((rc = ensure(c, c->rx_part_buf, (roff[c->n_ranks] + 16) * 4))) return rc;
+  if ((rc = ensure(c, c->rx_part_buf, (roff[c->n_ranks] + 16) * (c->part_pos ? 8 : 4)))) return rc;
   if ((rc = ensure(c, c->rx_ghist_buf, (size_t)c->n_ranks * rows * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->rx_segoff_buf, (size_t)c->n_ranks * rows * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->rx_roff, 8 * (P3_MAX_RANKS + 1)))) return rc;
@@ -793,6 +877,40 @@ int p3_mr_solid_build(p3_ctx* c, uint32_t rs_log2, void** d_solid, uint64_t* own
   *owned_bytes = (nsb_owned << rs_log2) * 4;
   *owned_offset_bytes = c->rank * *owned_bytes;
   *total_bytes = *owned_bytes * c->n_ranks;
+  HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+  return P3_OK;
+}
+
+int p3_mr_singles_layout(p3_ctx* c, void** d_singles, uint64_t* offsets, uint64_t* counts) {
+  if (!c || !d_singles || !offsets || !counts) return P3_EBADARG;
+  if (!c->part_pos) return fail(c, P3_ESTATE, "the partition carries no positions (gate_mode 1)");
+  HIPCHK(c, hipSetDevice(c->device));
+  u64 roff[P3_MAX_RANKS + 1];
+  HIPCHK(c, hipMemcpy(roff, c->rx_roff.p, 8 * (c->n_ranks + 1), hipMemcpyDeviceToHost));
+  *d_singles = c->singles.p;
+  for (u32 s = 0; s < c->n_ranks; s++) {
+    offsets[s] = roff[s];
+    counts[s] = c->sing_count[s];
+  }
+  return P3_OK;
+}
+
+int p3_mr_nonsolid_recv_alloc(p3_ctx* c, uint64_t total, void** d_buf) {
+  if (!c || !d_buf) return P3_EBADARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->ns_recv, (total + 16) * 4);
+  if (rc) return rc;
+  *d_buf = c->ns_recv.p;
+  return P3_OK;
+}
+
+int p3_mr_solid_bits(p3_ctx* c, uint64_t n_positions) {
+  if (!c) return P3_EBADARG;
+  if (!c->part_pos || !c->ns_recv.p) return fail(c, P3_ESTATE, "no received non-solid positions");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = solid_bits(c, (const u32*)c->ns_recv.p, n_positions);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
   return P3_OK;
 }

@@ -19,7 +19,8 @@ from . import capi
 STAGE_OF = {
     "k_pack": "count", "k_endmask": "count", "k_count_direct": "count", "k_count_compact": "count",
     "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count",
-    "k_solid_regions": "count",
+    "k_solid_regions": "count", "k_part_scatter_pos": "count", "k_u32_hist": "count", "k_u32_scatter": "count",
+    "k_solid_slices": "count",
     "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_bloom_insert": "bloom",
     "k_pos_hist": "bloom", "k_pos_scatter": "bloom", "k_bloom_slices": "bloom",
     "k_gate_direct": "bloom", "k_gate_regions": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
@@ -70,7 +71,8 @@ class HipBackend:
         lay = self.ctx.mr_count_send_layout()
         t = self.torch
         n_desc = 1024 * lay["row_u32"]
-        return dict(part=self.tensor(lay["d_part"], lay["rec_off"][-1], t.int32),
+        self._rec_dtype = t.int64 if lay["rec_bytes"] == 8 else t.int32
+        return dict(part=self.tensor(lay["d_part"], lay["rec_off"][-1], self._rec_dtype),
                     ghist=self.tensor(lay["d_ghist"], n_desc, t.int32),
                     segoff=self.tensor(lay["d_segoff"], n_desc, t.int32),
                     rec_off=lay["rec_off"], rows=lay["rows"], row_u32=lay["row_u32"])
@@ -79,7 +81,7 @@ class HipBackend:
         a, b, c = self.ctx.mr_count_recv_alloc(recv_records)
         t = self.torch
         n_desc = world * rows * row_u32
-        return (self.tensor(a, int(sum(recv_records)), t.int32), self.tensor(b, n_desc, t.int32),
+        return (self.tensor(a, int(sum(recv_records)), self._rec_dtype), self.tensor(b, n_desc, t.int32),
                 self.tensor(c, n_desc, t.int32))
 
     def mr_initial_sbits(self):
@@ -94,6 +96,21 @@ class HipBackend:
     def mr_solid_build(self, rs_log2):
         p, off, own, tot = self.ctx.mr_solid_build(rs_log2)
         return self.bytes_tensor(p, tot), off, own
+
+    def gate_mode(self):
+        """2 = return path (the partition records carry window positions), 1 = solid-region probes"""
+        return 2 if self._rec_dtype == self.torch.int64 else 1
+
+    def mr_singles_layout(self):
+        p, offs, cnts = self.ctx.mr_singles_layout()
+        total = max(o + c for o, c in zip(offs, cnts)) if offs else 0
+        return self.tensor(p, total, self.torch.int32), offs, cnts
+
+    def mr_nonsolid_recv_alloc(self, total):
+        return self.tensor(self.ctx.mr_nonsolid_recv_alloc(total), total, self.torch.int32)
+
+    def mr_solid_bits(self, n_positions):
+        self.ctx.mr_solid_bits(n_positions)
 
     def make_bloom(self, k, m, H):
         self.ctx.make_bloom(k, m, H)
@@ -176,13 +193,33 @@ class Pipeline:
             sbits += 1
             if sbits > 5:
                 raise capi.P3Error(3, "LDS count tables overflow at every sub-bucket split")
-        rs_log2 = be.rs_log2_for(allreduce_max(max_solid))
-        # -- gate: all-gather the owners' solid regions ------------------------------------------------------
-        solid, off, own = be.mr_solid_build(rs_log2)
-        if W > 1:
-            mine = solid[off:off + own].clone()
-            dist.all_gather_into_tensor(solid, mine, group=g)
+        if be.gate_mode() == 2:
+            # -- gate, return path: each owner sends the positions of the non-solid windows back to the rank
+            #    whose reads they index (list s -> rank s); no solid table is ever probed
+            singles, offs, cnts = be.mr_singles_layout()
+            sc2 = torch.tensor(cnts, dtype=torch.int64, device=dev)
+            rc2 = torch.empty_like(sc2)
+            if W > 1:
+                dist.all_to_all_single(rc2, sc2, group=g)
+            else:
+                rc2.copy_(sc2)
+            rcnts = [int(x) for x in rc2.tolist()]
+            buf = be.mr_nonsolid_recv_alloc(sum(rcnts))
+            send = torch.cat([singles[o:o + c] for o, c in zip(offs, cnts)]) if W > 1 else singles[offs[0]:offs[0] + cnts[0]]
+            if W > 1:
+                dist.all_to_all_single(buf, send, output_split_sizes=rcnts, input_split_sizes=cnts, group=g)
+            else:
+                buf.copy_(send)
             self._sync(dev)
+            be.mr_solid_bits(sum(rcnts))
+        else:
+            # -- gate, table form: all-gather the owners' solid regions ----------------------------------------
+            rs_log2 = be.rs_log2_for(allreduce_max(max_solid))
+            solid, off, own = be.mr_solid_build(rs_log2)
+            if W > 1:
+                mine = solid[off:off + own].clone()
+                dist.all_gather_into_tensor(solid, mine, group=g)
+                self._sync(dev)
         # -- Bloom: rank-local partial vector, then OR-merge ---------------------------------------------------
         be.make_bloom(k, m, H)
         if W > 1:

@@ -36,9 +36,23 @@ def unmix42(g):
 
 
 class CpuBackend:
-    def __init__(self, oracle):
+    def __init__(self, oracle, gate=2):
         self.o = oracle
+        self.gate = gate   # 2 = return path (records carry positions), 1 = solid-region table
         self.timing = {}
+
+    def gate_mode(self):
+        return self.gate
+
+    def _window_positions(self):
+        """start position (in this rank's concatenated bases) of every valid 21-mer window, in read order"""
+        bases, offs = self.reads
+        out = []
+        for r in range(offs.size - 1):
+            L = int(offs[r + 1] - offs[r])
+            if L >= self.min_len and L >= 21:
+                out.append(np.arange(int(offs[r]), int(offs[r]) + L - 20, dtype=np.uint64))
+        return np.concatenate(out) if out else np.zeros(0, np.uint64)
 
     def scalar_device(self):
         return "cpu"
@@ -56,14 +70,19 @@ class CpuBackend:
         g = mix42(keys)
         pb = (g >> np.uint64(32)).astype(np.int64)
         order = np.argsort(pb, kind="stable")
-        rec = (g & np.uint64(0xffffffff)).astype(np.uint32)[order]
+        if self.gate == 2:
+            self.win_keys = keys
+            self.win_pos = self._window_positions()
+            rec = ((self.win_pos << np.uint64(32)) | (g & np.uint64(0xffffffff)))[order]
+        else:
+            rec = (g & np.uint64(0xffffffff)).astype(np.uint32)[order]
         cnt = np.bincount(pb, minlength=NB).astype(np.int64)
         ghist = np.zeros((NB, NWG), np.uint32)
         segoff = np.zeros((NB, NWG), np.uint32)
         ghist[:, 0] = cnt          # everything in workgroup column 0
         padded = (cnt + 15) // 16 * 16
         base = np.concatenate([[0], np.cumsum(padded)])
-        part = np.full(int(base[-1]), 0xdeadbeef, np.uint32)  # holes hold garbage, like the real buffer
+        part = np.full(int(base[-1]), 0xdeadbeef, rec.dtype)  # holes hold garbage, like the real buffer
         src = np.concatenate([[0], np.cumsum(cnt)])
         for b in range(NB):
             part[base[b]:base[b] + cnt[b]] = rec[src[b]:src[b + 1]]
@@ -75,15 +94,15 @@ class CpuBackend:
     def mr_send_layout(self):
         rows = NB // self.world
         rec_off = [int(self.base[d * rows]) for d in range(self.world)] + [int(self.base[-1])]
-        return dict(part=torch.from_numpy(self.part.view(np.int32)), ghist=torch.from_numpy(self.ghist.reshape(-1).view(np.int32)),
+        return dict(part=torch.from_numpy(self.part.view(np.int64 if self.gate == 2 else np.int32)), ghist=torch.from_numpy(self.ghist.reshape(-1).view(np.int32)),
                     segoff=torch.from_numpy(self.segoff.reshape(-1).view(np.int32)), rec_off=rec_off, rows=rows, row_u32=NWG)
 
     def mr_recv_alloc(self, recv_records, rows, row_u32, world):
         self.recv_records = [int(x) for x in recv_records]
-        self.rpart = np.zeros(max(1, sum(self.recv_records)), np.uint32)
+        self.rpart = np.zeros(max(1, sum(self.recv_records)), np.uint64 if self.gate == 2 else np.uint32)
         self.rghist = np.zeros(world * rows * row_u32, np.uint32)
         self.rsegoff = np.zeros(world * rows * row_u32, np.uint32)
-        return (torch.from_numpy(self.rpart.view(np.int32))[:sum(self.recv_records)],
+        return (torch.from_numpy(self.rpart.view(np.int64 if self.gate == 2 else np.int32))[:sum(self.recv_records)],
                 torch.from_numpy(self.rghist.view(np.int32)), torch.from_numpy(self.rsegoff.view(np.int32)))
 
     def mr_initial_sbits(self):
@@ -95,16 +114,23 @@ class CpuBackend:
         gh = self.rghist.reshape(W, rows, NWG)
         so = self.rsegoff.reshape(W, rows, NWG)
         roff = np.concatenate([[0], np.cumsum(self.recv_records)])
-        gs = []
+        gs, srcs, poss = [], [], []
         for s in range(W):
             sbase = int(so[s, 0, 0])
             for r in range(rows):
                 for wg in np.nonzero(gh[s, r])[0]:
                     a = int(roff[s]) + int(so[s, r, wg]) - sbase
                     recs = self.rpart[a:a + int(gh[s, r, wg])].astype(np.uint64)
-                    gs.append((np.uint64(self.rank * rows + r) << np.uint64(32)) | recs)
+                    gs.append((np.uint64(self.rank * rows + r) << np.uint64(32)) | (recs & np.uint64(0xffffffff)))
+                    srcs.append(np.full(recs.size, s, np.int64))
+                    poss.append((recs >> np.uint64(32)).astype(np.uint32))
         g = np.concatenate(gs) if gs else np.zeros(0, np.uint64)
-        ug, cnt = np.unique(g, return_counts=True)
+        ug, inv, cnt = np.unique(g, return_inverse=True, return_counts=True)
+        if self.gate == 2:
+            single = cnt[inv] == 1   # instances that are the only one of their key
+            src = np.concatenate(srcs) if srcs else np.zeros(0, np.int64)
+            pos = np.concatenate(poss) if poss else np.zeros(0, np.uint32)
+            self.sing_lists = [np.sort(pos[single & (src == s)]) for s in range(W)]
         keys = unmix42(ug)
         order = np.argsort(keys)
         self.shard_keys, self.shard_counts = keys[order], cnt[order].astype(np.uint64)
@@ -113,6 +139,23 @@ class CpuBackend:
         sb = (self.owned_g_solid >> np.uint64(32 - sbits)).astype(np.int64)
         max_solid = int(np.bincount(sb).max()) if sb.size else 0
         return 0, max_solid
+
+    def mr_singles_layout(self):
+        roff = np.concatenate([[0], np.cumsum(self.recv_records)]).astype(np.int64)
+        buf = np.zeros(max(1, int(roff[-1])), np.uint32)
+        cnts = []
+        for s, lst in enumerate(self.sing_lists):   # list s sits at the start of source s's region, like the library
+            buf[roff[s]:roff[s] + lst.size] = lst
+            cnts.append(int(lst.size))
+        self._singles = buf
+        return torch.from_numpy(buf.view(np.int32)), [int(x) for x in roff[:-1]], cnts
+
+    def mr_nonsolid_recv_alloc(self, total):
+        self.ns_recv = np.zeros(max(1, total), np.uint32)
+        return torch.from_numpy(self.ns_recv.view(np.int32))[:total]
+
+    def mr_solid_bits(self, n_positions):
+        self.nonsolid = np.unique(self.ns_recv[:n_positions].astype(np.uint64))
 
     def rs_log2_for(self, max_solid):
         want = max_solid + (max_solid * 3) // 5 + 1
@@ -142,6 +185,18 @@ class CpuBackend:
 
     # -- Bloom ------------------------------------------------------------------------------------------------
     def make_bloom(self, k, m, H):
+        if self.gate == 2:
+            # this rank's own windows: count 1 where the owner reported the position as non-solid, else "2"
+            is_ns = np.isin(self.win_pos, self.nonsolid)
+            uk, first = np.unique(self.win_keys, return_index=True)
+            cnt = np.where(is_ns[first], 1, 2).astype(np.uint64)
+            words, seeds, _, _ = self.o.make_bf(self.reads, uk, cnt, k, m, H, min_len=self.min_len)
+            n = (words.size + self.world - 1) // self.world * self.world
+            self.bloom = np.zeros(n, np.uint64)
+            self.bloom[:words.size] = words
+            self.n_bloom_words = words.size
+            self.seeds = seeds
+            return
         sbits, RS = self.sbits, 1 << self.rs_log2
         table = self.solid.reshape(NB << sbits, RS)
         sb_idx, slot = np.nonzero(table != 0xffffffff)

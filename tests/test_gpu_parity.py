@@ -140,18 +140,22 @@ def test_idempotent_rerun(ctx, oracle):
     assert np.array_equal(k1[0], k2[0]) and np.array_equal(k1[1], k2[1])
 
 
+@pytest.mark.parametrize("gate", [1, 2])
 @pytest.mark.parametrize("mode,ts_log2,expect_mode", [(1, 14, 1), (2, 14, 2), (0, 8, 2), (0, 5, 1)])
-def test_count_paths(oracle, mode, ts_log2, expect_mode):
+def test_count_paths(oracle, mode, ts_log2, expect_mode, gate):
     """direct global-table path, partitioned LDS path, partitioned with a re-split after LDS-table overflow
     (ts_log2=8), and overflow at every split -> fallback to direct (ts_log2=5): identical results."""
     c = capi.Context(0)
     try:
         c.set_option("count_mode", mode)
         c.set_option("ts_log2", ts_log2)
+        c.set_option("gate_mode", gate)  # 1 = solid-table probes, 2 = return path (positions in the records)
         b, o = synth.reads(seed=21, total_reads=30000, read_len=150)
         m, H = oracle.estimate_bloom(int(b.size), 31)
         run_and_compare(c, oracle, (b, o), 31, m, H)
         assert c.get_info("count_mode") == expect_mode
+        if expect_mode == 2:
+            assert c.get_info("gate_mode") == gate
         if ts_log2 == 8:
             assert c.get_info("sbits") > 1
     finally:
@@ -181,7 +185,8 @@ def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
         c.close()
 
 
-def test_protocol_single_rank(oracle):
+@pytest.mark.parametrize("gate", [1, 2])
+def test_protocol_single_rank(oracle, gate):
     """The multi-rank protocol (partition -> owners count -> solid regions -> rank-local Bloom) driven with
     one rank and no process group: same results as the single-call pass."""
     from platanus3_amd.pipeline import Pipeline
@@ -189,6 +194,7 @@ def test_protocol_single_rank(oracle):
     k = 31
     m, H = oracle.estimate_bloom(int(b.size), k)
     pipe = Pipeline(device=0, rank=0, world=1, force_protocol=True)
+    pipe.ctx.set_option("gate_mode", gate)
     pipe.load_reads(b, o, min_len=k)
     pipe.run_pass(k, m, H)
     c = pipe.ctx

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, n_reads, tmpdir):
+def _worker(rank, world, port, k, n_reads, tmpdir, gate):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, k, n_reads, tmpdir):
         per = n_reads // world
         b, offs = synth.reads(seed=5, total_reads=n_reads, first_read=rank * per, n_reads=per, read_len=150)
         m, H = o.estimate_bloom(n_reads * 150, k)
-        be = CpuBackend(o)
+        be = CpuBackend(o, gate=gate)
         pipe = Pipeline(rank=rank, world=world, backend=be)
         pipe.load_reads(b, offs, min_len=k)
         pipe.run_pass(k, m, H)
@@ -53,12 +53,12 @@ def _worker(rank, world, port, k, n_reads, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k", [(2, 31), (4, 25), (2, 47)])
-def test_sharded_pass_equals_single_rank(tmp_path, oracle, world, k):
+@pytest.mark.parametrize("world,k,gate", [(2, 31, 2), (4, 25, 2), (2, 47, 1), (4, 31, 1)])
+def test_sharded_pass_equals_single_rank(tmp_path, oracle, world, k, gate):
     import platanus3_amd.synth as synth
     n_reads = 1200
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, k, n_reads, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, k, n_reads, str(tmp_path), gate), nprocs=world, join=True)
     b, offs = synth.reads(seed=5, total_reads=n_reads, read_len=150)
     m, H = oracle.estimate_bloom(n_reads * 150, k)
     ekeys, ecounts = oracle.count_short((b, offs), min_len=k)
