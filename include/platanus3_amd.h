@@ -67,7 +67,7 @@ int p3_set_profiling(p3_ctx* ctx, int on);
  *                 2 = dedup (H probes per distinct passing k-mer; error if it cannot be used)
  *   "bloom_slices" 1 (default) = after dedup, probe positions are partitioned by bit-vector slice and OR-ed
  *                 in LDS (bloom_mode reads back 3); 0 = global atomicOr per probe (bloom_mode 2)
- *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 13)
+ *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 14; 2-word keys use 2 less)
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
  * "rs_log2", "distinct_kmers". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);

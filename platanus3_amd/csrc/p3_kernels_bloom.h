@@ -224,7 +224,7 @@ template <int NW>
 __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off, const u32* __restrict__ ghist,
                                                      u32 sbits, u32 ts_log2, u64* __restrict__ out_keys,
-                                                     u64* __restrict__ gstats) {
+                                                     u64* __restrict__ gstats, u32 dbg) {
   typedef typename KRec<NW>::type REC;
   constexpr u32 CHUNK = Stg<REC>::CHUNK;
   extern __shared__ __align__(16) u32 lds[];
@@ -249,6 +249,11 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
   (void)CHUNK;
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
   // slot / sub-bucket hash: the full 64-bit mix only when a sub-bucket split needs the scatter's bucket bits
+  auto fold32 = [&](u64 lo, u64 hi) -> u32 {
+    u32 x = (u32)lo ^ (u32)(lo >> 32);
+    if (NW == 2) x ^= (u32)hi * 0x85EBCA6Bu ^ (u32)(hi >> 32);
+    return x;
+  };
   auto slot_of = [&](u64 lo, u64 hi, bool& mine) -> u32 {
     mine = true;
     if (sbits) {
@@ -256,11 +261,11 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
       mine = ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
       return (u32)(h >> 16) & (TS - 1);
     }
-    u32 x = (u32)lo ^ (u32)(lo >> 32);
-    if (NW == 2) x ^= (u32)hi * 0x85EBCA6Bu ^ (u32)(hi >> 32);
-    return (x * 0x9E3779B1u) >> (32 - ts_log2);
+    return (fold32(lo, hi) * 0x9E3779B1u) >> (32 - ts_log2);
   };
   auto slow_insert = [&](u64 lo, u64 hi, u32 slot) {
+    // double hashing (odd step): short probe chains -> short drain rounds (see k_part_count)
+    const u32 step = ((fold32(lo, hi) * 0xC2B2AE35u) >> 15) | 1u;
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       if constexpr (NW == 1) {
@@ -311,16 +316,16 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
           break;
         }
       }
-      slot = (slot + 1) & (TS - 1);
+      slot = (slot + step) & (TS - 1);
     }
     if (!placed) sc[6] = 1;  // table (nearly) full: the host re-splits or falls back
   };
   // Same structure as k_part_count: uniform home-slot check, misses through a per-wave LDS queue that is
   // drained 64 items at a time so the data-dependent probe loop always runs with full lanes.
   constexpr int NBATCH = 4 * (16 / sizeof(REC));
-  constexpr int G = (NW == 1) ? 4 : 2;              // records per lane between drains
+  constexpr int G = 2;                              // records per lane between drains
   constexpr u32 QCAP = 64 * G + 64;                 // 63 left over + 64*G new
-  REC* wq = reinterpret_cast<REC*>(valid + P3_VALID_CAP) + (threadIdx.x >> 6) * QCAP;
+  REC* wq = reinterpret_cast<REC*>(valid + P3_VCAP_POS) + (threadIdx.x >> 6) * QCAP;
   u32 qn = 0;  // wave-uniform
   const u32 lane_id = threadIdx.x & 63;
   const unsigned long long lt_mask = (1ULL << lane_id) - 1;
@@ -335,7 +340,17 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
     const u32 slot = slot_of(lo, hi, mine);
     slow_insert(lo, hi, slot);
   };
-  bucket_for_each<REC>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+  bucket_for_each<REC, P3_VCAP_POS>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+    if (dbg & 2) {  // timing experiment: read only
+      u64 x = 0;
+#pragma unroll
+      for (int i = 0; i < NBATCH; i++) {
+        if constexpr (NW == 1) x ^= r[i];
+        else x ^= r[i].lo;
+      }
+      if (x == 0x1234567 && act == 77) sc[7] = 1;
+      return;
+    }
 #pragma unroll
     for (int g0 = 0; g0 < NBATCH; g0 += G) {
       u64 lo[G], hi[G], cur_lo[G], cur_hi[G];
@@ -370,6 +385,7 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
         qn += (u32)__popcll(bal);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (dbg & 1) qn = 0;  // timing experiment: drop the misses
       while (qn >= 64) {
         qn -= 64;
         const REC it = wq[qn + lane_id];

@@ -294,7 +294,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u64* __restrict__ out_keys, u32* __restrict__ out_counts,
                                                      uint4* __restrict__ sb_info, u64* __restrict__ gstats,
                                                      u32* __restrict__ tpos, uint8_t* __restrict__ tsrc,
-                                                     u32* __restrict__ singles, u64* __restrict__ sing_cursor) {
+                                                     u32* __restrict__ singles, u64* __restrict__ sing_cursor,
+                                                     u32 dbg) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
   constexpr u32 VCAP = POS ? P3_VCAP_POS : P3_VALID_CAP;
   constexpr u32 QCAP = POS ? P3_WQ_CAP_POS : P3_WQ_CAP;
@@ -327,10 +328,15 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   }
   if (threadIdx.x < 128) sc[16 + threadIdx.x] = 0;
   __syncthreads();
-  const u32 sb = blockIdx.x;           // owned (local) sub-bucket index
-  const u32 pb_local = sb >> sbits;
-  const u32 pb = first_pb + pb_local;  // global bucket id (key reconstruction)
-  const u32 subsel = sb & ((1u << sbits) - 1);
+  // XCD-aware block -> (bucket, sub-bucket) map: the 2^sbits workgroups that stream the SAME bucket get block
+  // ids that are equal mod 8, i.e. (as observed, not relied on) the same XCD at about the same time, so all but
+  // the first reader of a bucket hit that XCD's L2 instead of HBM.  Placement only affects speed.
+  const u32 nsub = 1u << sbits;
+  const u32 grp = blockIdx.x / (8u * nsub), rr = blockIdx.x % (8u * nsub);
+  const u32 pb_local = grp * 8u + (rr & 7u);
+  const u32 subsel = rr >> 3;
+  const u32 sb = pb_local * nsub + subsel;  // owned (local) sub-bucket index
+  const u32 pb = first_pb + pb_local;        // global bucket id (key reconstruction)
   const u32 rem_bits = 32 - sbits;
   const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
   const u32 lane = threadIdx.x & 63;
@@ -341,6 +347,9 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   auto slow_insert = [&](REC item) {
     const u32 rem = (u32)item & rem_mask;
     u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
+    // double hashing (odd step, power-of-two table): no primary clustering, so the longest chain among the 64
+    // lanes of a drain round -- which is what the round costs -- stays short
+    const u32 step = ((rem * 0x85EBCA6Bu) >> 15) | 1u;
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       u32 old = tkey[slot];
@@ -360,7 +369,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         placed = true;
         break;
       }
-      slot = (slot + 1) & (TS - 1);
+      slot = (slot + step) & (TS - 1);
     }
     if (!placed) s_ovf = 1;  // table (nearly) full: the host re-splits or falls back
   };
@@ -375,6 +384,13 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     const u32 row = src * rows + pb_local;
     const REC* part_src = part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
     bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+      if (dbg & 2) {  // timing experiment: read only
+        u64 x = 0;
+#pragma unroll
+        for (int i = 0; i < NBATCH; i++) x ^= (u64)r[i];
+        if (x == 0x1234567 && act == 77) s_ovf = 1;
+        return;
+      }
 #pragma unroll
       for (int g0 = 0; g0 < NBATCH; g0 += G) {
         u32 rem[G], slot[G], cur[G];
@@ -396,6 +412,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           qn += (u32)__popcll(bal);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (dbg & 1) qn = 0;  // timing experiment: drop the misses
         while (qn >= 64) {
           qn -= 64;
           slow_insert(wq[qn + lane]);
@@ -416,7 +433,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   }
   __syncthreads();
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
-  u32 my_solid = 0, my_max = 0;
+  if (dbg & 4) return;  // timing experiment: no emission
+  u32 my_solid = 0, my_max = 0, my_single = 0;
   for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {  // TS is a multiple of the block size or smaller than it
     const u32 i = i0 + threadIdx.x;
     const u32 rem = (i < TS) ? tkey[i] : P3_EMPTY32;
@@ -434,7 +452,14 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       my_solid += (c >= 2);
       my_max = c > my_max ? c : my_max;
       if constexpr (POS)
-        if (c == 1) atomicAdd(&s_sing[(n_src > 1) ? tsrc[tbase + i] : 0u], 1u);
+        if (c == 1 && n_src > 1) atomicAdd(&s_sing[tsrc[tbase + i]], 1u);
+      my_single += (c == 1);
+    }
+  }
+  if constexpr (POS) {
+    if (n_src == 1) {
+      for (int off = 32; off > 0; off >>= 1) my_single += __shfl_down(my_single, off, 64);
+      if (lane == 0 && my_single) atomicAdd(&s_sing[0], my_single);
     }
   }
   if constexpr (POS) {
@@ -445,11 +470,23 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       s_sing[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
-      if (tkey[i] != P3_EMPTY32 && tcnt[i] == 1) {
-        const u32 src = (n_src > 1) ? tsrc[tbase + i] : 0u;
-        const u32 idx = atomicAdd(&s_sing[src], 1u);
-        singles[roff[src] + s_singbase[src] + idx] = tpos[tbase + i];
+    if (n_src == 1) {
+      for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {  // one LDS atomic per wave (ballot prefix)
+        const u32 i = i0 + threadIdx.x;
+        const bool one = (i < TS) && tkey[i] != P3_EMPTY32 && tcnt[i] == 1;
+        const unsigned long long bal = __ballot(one);
+        u32 wbase = 0;
+        if (lane == 0 && bal) wbase = atomicAdd(&s_sing[0], (u32)__popcll(bal));
+        wbase = __shfl(wbase, 0, 64);
+        if (one) singles[roff[0] + s_singbase[0] + wbase + (u32)__popcll(bal & ((1ULL << lane) - 1))] = tpos[tbase + i];
+      }
+    } else {
+      for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+        if (tkey[i] != P3_EMPTY32 && tcnt[i] == 1) {
+          const u32 src = tsrc[tbase + i];
+          const u32 idx = atomicAdd(&s_sing[src], 1u);
+          singles[roff[src] + s_singbase[src] + idx] = tpos[tbase + i];
+        }
       }
     }
   }

@@ -66,7 +66,8 @@ struct p3_ctx {
   bool ccounts_u32 = false;
   int bloom_mode_opt = 0;   // 0 auto, 1 direct (one insert per window), 2 dedup (one insert per distinct k-mer)
   int bloom_mode = 0;
-  int tsk_log2_opt = 13;    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
+  int tsk_log2_opt = 14;
+  int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0;
   DevBuf kpart, dkeys, ppart, scan_tmp;
   // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
@@ -356,14 +357,14 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->rx_part,
                (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u32*)c->tpos.p, (uint8_t*)c->tsrc.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p);
+               (u32*)c->tpos.p, (uint8_t*)c->tsrc.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)c->rx_part,
                (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u32*)nullptr, (uint8_t*)nullptr, (u32*)nullptr, (u64*)nullptr);
+               (u32*)nullptr, (uint8_t*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
   }
   u64 h[8];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
@@ -539,7 +540,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
                (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->P.p, c->n_words, k,
                (const u32*)c->seg_off.p, (REC*)c->kpart.p);
-    u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 1 : 0);
+    u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 2 : 0);  // 16 Ki x 8 B or 4 Ki x 20 B slots
     u32 sbits = 0;
     while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
     for (;; sbits++) {
@@ -549,10 +550,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       }
       const u32 nsb = P3_NB << sbits;
       HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VALID_CAP +
-                         16 * (NW == 1 ? 320 * 8 : 192 * 16);
+      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
+                         16 * 192 * sizeof(REC);
       LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), nsb, 1024, lds, (const REC*)c->kpart.p,
-                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st);
+                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st, (u32)c->dbg_opt);
       HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (h[3] == 0) break;
@@ -706,8 +707,10 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     c->bloom_mode_opt = (int)value;
   } else if (n == "bloom_slices") {
     c->bloom_slices_opt = value != 0;
+  } else if (n == "dbg") {
+    c->dbg_opt = (int)value;
   } else if (n == "tsk_log2") {
-    if (value < 4 || value > 13) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,13]");
+    if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
   } else if (n == "ts_log2") {
     if (value < 4 || value > P3_TS_LOG2_MAX) return fail(c, P3_EBADARG, "ts_log2 must be in [4,%d]", P3_TS_LOG2_MAX);

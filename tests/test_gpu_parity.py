@@ -162,8 +162,8 @@ def test_count_paths(oracle, mode, ts_log2, expect_mode, gate):
         c.close()
 
 
-@pytest.mark.parametrize("k,mode,tsk,expect_mode", [(31, 1, 13, 1), (31, 2, 13, 3), (31, 0, 7, 3), (31, 0, 4, 1),
-                                                    (63, 2, 13, 3), (63, 0, 7, 3), (41, 1, 13, 1), (31, -2, 13, 2),
+@pytest.mark.parametrize("k,mode,tsk,expect_mode", [(31, 1, 14, 1), (31, 2, 14, 3), (31, 0, 7, 3), (31, 0, 4, 1),
+                                                    (63, 2, 14, 3), (63, 0, 8, 3), (41, 1, 14, 1), (31, -2, 14, 2),
                                                     (63, -2, 13, 2)])
 def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
     """direct (probe per window) vs dedup (probe per distinct k-mer) Bloom build, including LDS-set overflow
@@ -179,7 +179,7 @@ def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
         m, H = oracle.estimate_bloom(int(b.size), k)
         run_and_compare(c, oracle, (b, o), k, m, H)
         assert c.get_info("bloom_mode") == expect_mode
-        if tsk == 7:
+        if tsk in (7, 8):
             assert c.get_info("ksbits") > 0
     finally:
         c.close()
@@ -206,3 +206,48 @@ def test_protocol_single_rank(oracle, gate):
     assert np.array_equal(c.export_bloom(), ebloom)
     assert [capi.decode_key(r, k) for r in c.export_seeds()] == eseeds
     c.close()
+
+
+def test_config2_full_size_against_reference_checksums(ctx):
+    """BASELINE config #2 at FULL size (1 M x 150 bp, k=31): sha256 of the exported count table, Bloom words
+    (default sizing and the '-m 2^30' H=10 run) and seed list against checksums the REAL reference produced on
+    the same generator output (tests/golden/make_golden_config2.py, ~6 min of reference CPU time), plus
+    size-independent properties (sum of counts = windows; every seed queries positive)."""
+    import hashlib
+    import json
+    import os
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, "config2_checksums.json")) as f:
+        g = json.load(f)
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    k = g["k"]
+    b, o = synth.reads(seed=g["seed"], total_reads=g["n_reads"], read_len=g["read_len"])
+    ctx.load_reads(b, o, min_len=k)
+    st = ctx.count_short()
+    assert st["n_distinct"] == g["n_distinct"] and st["n_solid"] == g["n_solid"]
+    assert st["n_windows"] == g["n_windows"] and st["max_count"] == g["max_count"]
+    keys, counts = ctx.export_counts()
+    assert int(counts.sum()) == g["n_windows"]
+    assert sha(keys) == g["keys_sha256"] and sha(counts) == g["counts_sha256"]
+    for run in g["runs"]:
+        ctx.make_bloom(k, run["m"], run["H"])
+        words = ctx.export_bloom()
+        assert int(np.unpackbits(words.view(np.uint8)).sum()) == run["bits_set"]
+        assert sha(words) == run["bloom_sha256"]
+        seeds = ctx.export_seeds()
+        assert seeds.shape[0] == run["n_seeds"]
+        sk = seeds[:, 0]
+        chars = np.empty((sk.size, k), np.uint8)
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        for i in range(k):
+            chars[:, i] = lut[((sk >> np.uint64(2 * (k - 1 - i))) & np.uint64(3)).astype(np.int64)]
+        assert sha(chars) == run["seeds_sha256"]
+        # B2 property: the canonical form of every (sampled) seed is in the filter
+        samp = sk[:: max(1, sk.size // 4096)]
+        rc = np.zeros_like(samp)
+        for i in range(k):
+            rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
+        assert ctx.bloom_query(np.minimum(samp, rc)).all()
