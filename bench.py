@@ -113,8 +113,21 @@ def main():
 
     for _ in range(args.warmup):
         pipe.run_pass(k, m, H)
+    # One extra untimed pass with HIP events around EVERY launch: per-kernel split + which kernel dominates.
+    # (A bracket costs ~10 us of stream time, ~0.45 ms per pass if all ~45 launches carried one, so the timed
+    # steps below bracket only the dominant kernel.)
     pipe.ctx.reset_kernel_stats()
-    pipe.ctx.set_profiling(True)  # HIP events around every kernel launch, on the library's own stream
+    pipe.ctx.set_profiling(True)
+    pipe.run_pass(k, m, H)
+    pipe.ctx.set_profiling(False)
+    split = pipe.ctx.kernel_stats()
+    dom_name = max(split.items(), key=lambda kv: kv[1]["total_ms"])[0] if split else None
+    if world > 1:  # every rank must bracket the same kernel (identical programs; agree on rank 0's choice anyway)
+        obj = [dom_name]
+        dist.broadcast_object_list(obj, src=0)
+        dom_name = obj[0]
+    pipe.ctx.reset_kernel_stats()
+    pipe.ctx.set_profiling(True, only=dom_name)  # live HIP-event timing of the dominant kernel in the timed region
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -140,7 +153,7 @@ def main():
         b_alg_kmer = b_alg_read / (L - k + 1)
         # split by stage so a kernel is only credited with the bytes of the stage it implements
         stage_bytes = pipe.stage_alg_bytes(L, D, R, m)
-        dom_name, dom = max(stats.items(), key=lambda kv: kv[1]["total_ms"]) if stats else ("none", None)
+        dom = stats.get(dom_name)
         roof = None
         if dom:
             avg_ms = dom["total_ms"] / dom["launches"]
@@ -151,7 +164,7 @@ def main():
                     "alg_bytes_per_launch": per_launch_bytes,
                     "pass_alg_bytes_per_kmer": b_alg_kmer,
                     "pass_frac": (value / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
-                    "kernels_ms_per_step": {n: s["total_ms"] / args.steps for n, s in sorted(stats.items())}}
+                    "kernels_ms_per_step": {n: s["total_ms"] for n, s in sorted(split.items())}}
         out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d" % k, "value": value, "unit": "k-mers/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",

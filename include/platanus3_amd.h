@@ -54,6 +54,9 @@ const char* p3_last_error(const p3_ctx* ctx);
 int p3_device_count(void);
 /* 1 = record HIP events around every kernel launch (per-kernel stats below); 0 = off (default). */
 int p3_set_profiling(p3_ctx* ctx, int on);
+/* Restrict the event bracketing to launches of ONE kernel (by the name p3_kernel_stat reports); NULL or ""
+ * = all kernels.  Every bracket costs ~10 us of stream time, so timed runs profile only the kernel they need. */
+int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
 
 /* Tuning / test knobs (not needed for normal use):
  *   "count_mode"  0 = auto (partitioned LDS count when the input fits, else direct), 1 = force the direct

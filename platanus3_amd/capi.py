@@ -70,6 +70,7 @@ def load(build=False):
     L.p3_last_error.argtypes = [vp]
     L.p3_device_count.restype = C.c_int
     L.p3_set_profiling.argtypes = [vp, C.c_int]
+    L.p3_set_profile_filter.argtypes = [vp, C.c_char_p]
     L.p3_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.p3_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.p3_load_reads.argtypes = [vp, vp, vp, u64, u32]
@@ -286,7 +287,8 @@ class Context:
         return p.value
 
     # ---- timings ------------------------------------------------------------------------------------
-    def set_profiling(self, on):
+    def set_profiling(self, on, only=None):
+        self._chk(self.L.p3_set_profile_filter(self.h, only.encode() if only else None))
         self._chk(self.L.p3_set_profiling(self.h, 1 if on else 0))
 
     def timings(self):

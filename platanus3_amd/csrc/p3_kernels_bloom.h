@@ -425,8 +425,9 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
 
 // ---- k_bloom_insert: H probes per distinct key, global atomicOr -------------------------------------------------
 template <int NW>
-__global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
-                                                      u32* __restrict__ bloom) {
+__global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, const u64* __restrict__ n_ptr, u32 k,
+                                                      ModM mm, u32 H, u32* __restrict__ bloom) {
+  const u64 n = *n_ptr;
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
@@ -453,8 +454,10 @@ __device__ __forceinline__ void pos_key_range(u64 n, u32 wg, u64& begin, u64& en
 }
 
 template <int NW>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
-                                                              u32 slice_log2, u32* __restrict__ ghist) {
+__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+                                                              u32 k, ModM mm, u32 H, u32 slice_log2,
+                                                              u32* __restrict__ ghist) {
+  const u64 n = *n_ptr;  // number of distinct keys, left on the device by k_kmer_dedup
   __shared__ u32 hist[P3_NB];
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
   __syncthreads();
@@ -475,9 +478,18 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restr
 }
 
 template <int NW>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, u64 n, u32 k, ModM mm,
-                                                                 u32 H, u32 slice_log2, const u32* __restrict__ seg_off,
-                                                                 u32* __restrict__ out) {
+// totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
+// raises *cap_flag and writes nothing (the host re-runs with a larger buffer).
+__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+                                                                 u32 k, ModM mm, u32 H, u32 slice_log2,
+                                                                 const u32* __restrict__ seg_off, u32* __restrict__ out,
+                                                                 const u64* __restrict__ totals, u64 cap,
+                                                                 u64* __restrict__ cap_flag) {
+  if (totals[1] > cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cap_flag = 1;
+    return;
+  }
+  const u64 n = *n_ptr;
   constexpr u32 CAP = Stg<u32>::CAP;
   constexpr u32 PR = 8;  // probes per lane per round
   extern __shared__ __align__(16) u32 lds[];
@@ -544,7 +556,8 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
 // writes it in this mode).  n_u32 = number of u32 words of the whole vector.
 __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
-                                                       u32* __restrict__ bloom) {
+                                                       u32* __restrict__ bloom, const u64* __restrict__ cap_flag) {
+  if (*cap_flag) return;  // the probe partition did not fit: the host repeats the stage
   extern __shared__ __align__(16) u32 lds[];
   const u32 words = 1u << (slice_log2 - 5);
   u32* bm = lds;

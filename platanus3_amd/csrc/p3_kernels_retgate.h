@@ -100,8 +100,10 @@ __device__ __forceinline__ void u32_range(u64 n, u32 wg, u64& begin, u64& end) {
   if (end > n) end = n;
 }
 
-__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restrict__ vals, u64 n, u32 shift,
-                                                              u32* __restrict__ ghist) {
+// (the element count is read from device memory so that the host need not synchronise to learn it)
+__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
+                                                              u32 shift, u32* __restrict__ ghist) {
+  const u64 n = *n_ptr;
   __shared__ u32 hist[P3_NB];
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
   __syncthreads();
@@ -112,8 +114,10 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restr
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
 }
 
-__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __restrict__ vals, u64 n, u32 shift,
-                                                                 const u32* __restrict__ seg_off, u32* __restrict__ out) {
+__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
+                                                                 u32 shift, const u32* __restrict__ seg_off,
+                                                                 u32* __restrict__ out) {
+  const u64 n = *n_ptr;
   constexpr u32 CAP = Stg<u32>::CAP;
   constexpr u32 VR = 4;  // values per lane per round
   extern __shared__ __align__(16) u32 lds[];

@@ -39,6 +39,7 @@ struct p3_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   bool profiling = false;
+  std::string profile_only;  // when non-empty, only launches with this name are bracketed by events
   std::vector<KStat> kstats;
 
   // reads
@@ -83,6 +84,10 @@ struct p3_ctx {
   DevBuf part8, tpos, tsrc, singles, sing_cursor, ns_recv, ns_part;
   u64 sing_count[P3_MAX_RANKS] = {0};
   bool s_ready = false;
+  // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
+  bool spec = false, hint_valid = false;
+  u32 hint_sbits = 1, hint_ksbits = 0, hint_k = 0, hint_H = 0;
+  u64 hint_m = 0, reads_epoch = 0, hint_epoch = 0;
   int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
 
@@ -98,6 +103,8 @@ struct p3_ctx {
 };
 
 namespace {
+
+constexpr int P3_ERETRY_INTERNAL = 1000;  // never crosses the ABI
 
 int fail(p3_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -166,14 +173,15 @@ int drain_stats(p3_ctx* c) {
 #define LAUNCH(c, name, kernel, grid, block, ...)                                          \
   do {                                                                                     \
     hipEvent_t e0_ = nullptr, e1_ = nullptr;                                               \
-    if ((c)->profiling) {                                                                  \
+    const bool prof_ = (c)->profiling && ((c)->profile_only.empty() || (c)->profile_only == name); \
+    if (prof_) {                                                                           \
       HIPCHK(c, hipEventCreate(&e0_));                                                     \
       HIPCHK(c, hipEventCreate(&e1_));                                                     \
       HIPCHK(c, hipEventRecord(e0_, (c)->stream));                                         \
     }                                                                                      \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__);      \
     HIPCHK(c, hipGetLastError());                                                          \
-    if ((c)->profiling) {                                                                  \
+    if (prof_) {                                                                           \
       HIPCHK(c, hipEventRecord(e1_, (c)->stream));                                         \
       KStat* s_ = stat_for(c, name);                                                       \
       s_->launches++;                                                                      \
@@ -183,17 +191,24 @@ int drain_stats(p3_ctx* c) {
 
 #define LAUNCH_LDS(c, name, kernel, grid, block, ldsbytes, ...)                                  \
   do {                                                                                           \
-    HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)(ldsbytes)));                                             \
+    {                                                                                            \
+      static size_t attr_bytes_ = 0; /* per call site: raise the limit only when it grows */     \
+      if ((size_t)(ldsbytes) > attr_bytes_) {                                                    \
+        HIPCHK(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)(ldsbytes)));                                         \
+        attr_bytes_ = (size_t)(ldsbytes);                                                        \
+      }                                                                                          \
+    }                                                                                            \
     hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                     \
-    if ((c)->profiling) {                                                                        \
+    const bool prof_ = (c)->profiling && ((c)->profile_only.empty() || (c)->profile_only == name); \
+    if (prof_) {                                                                                 \
       HIPCHK(c, hipEventCreate(&e0_));                                                           \
       HIPCHK(c, hipEventCreate(&e1_));                                                           \
       HIPCHK(c, hipEventRecord(e0_, (c)->stream));                                               \
     }                                                                                            \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (ldsbytes), (c)->stream, __VA_ARGS__);   \
     HIPCHK(c, hipGetLastError());                                                                \
-    if ((c)->profiling) {                                                                        \
+    if (prof_) {                                                                                 \
       HIPCHK(c, hipEventRecord(e1_, (c)->stream));                                               \
       KStat* s_ = stat_for(c, name);                                                             \
       s_->launches++;                                                                            \
@@ -231,6 +246,8 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->min_len = min_len;
   c->have_reads = true;
   c->packed = c->counted = c->bloomed = false;
+  c->reads_epoch++;
+  c->hint_valid = false;
   return P3_OK;
 }
 
@@ -261,7 +278,7 @@ int do_count_direct(p3_ctx* c) {
   if ((rc = ensure(c, c->tcounts, cap * 8))) return rc;
   HIPCHK(c, hipMemsetAsync(c->tkeys.p, 0xff, cap * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(c->tcounts.p, 0, cap * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
   u64* st = (u64*)c->dstats.p;
   LAUNCH(c, "k_count_direct", k_count_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u64*)c->tkeys.p, (u64*)c->tcounts.p, cap - 1, st + 3);
@@ -316,7 +333,7 @@ int part_local(p3_ctx* c, bool with_pos) {
     if ((rc = ensure(c, c->part, max_records * 4))) return rc;
   }
   u64* st = (u64*)c->dstats.p;
-  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 16 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
   LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
   if ((rc = do_scan(c, st + 5))) return rc;  // totals at st[5..7]
@@ -366,12 +383,18 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
                c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                (u32*)nullptr, (uint8_t*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
   }
+  c->sbits = sbits;
+  c->ccounts_u32 = true;
+  if (c->spec) {  // checked at the single synchronisation point at the end of the pass
+    *overflowed = false;
+    *max_solid_sb = 0;
+    return P3_OK;
+  }
   u64 h[8];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
-  c->sbits = sbits;
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[2];
@@ -399,7 +422,7 @@ int solid_build(p3_ctx* c, u32 rs_log2) {
 }
 
 // (3') return path: S from the list of non-solid window positions (no table probes)
-int solid_bits(p3_ctx* c, const u32* d_positions, u64 n_pos) {
+int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_bound) {
   int rc;
   const u64 nwa = c->n_words + P3_PAD_WORDS;
   const u64 n_bits = c->n_words * 32;
@@ -408,14 +431,14 @@ int solid_bits(p3_ctx* c, const u32* d_positions, u64 n_pos) {
   if (slice_log2 > 20) return fail(c, P3_ECAPACITY, "window bitmap too large for the return-path gate");
   const u32 ns = (u32)((n_bits + ((1ull << slice_log2) - 1)) >> slice_log2);
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
-  if ((rc = ensure(c, c->ns_part, (n_pos + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+  if ((rc = ensure(c, c->ns_part, (n_pos_bound + 16ull * P3_NWG * P3_NB) * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 12, 0, 3 * 8, c->stream));
-  LAUNCH(c, "k_u32_hist", k_u32_hist, P3_NWG, P3_PART_THREADS, d_positions, n_pos, slice_log2, (u32*)c->ghist.p);
+  LAUNCH(c, "k_u32_hist", k_u32_hist, P3_NWG, P3_PART_THREADS, d_positions, d_n_pos, slice_log2, (u32*)c->ghist.p);
   if ((rc = do_scan(c, st + 12))) return rc;
   const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
-  LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, n_pos, slice_log2,
+  LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
              (const u32*)c->seg_off.p, (u32*)c->ns_part.p);
   const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
   LAUNCH_LDS(c, "k_solid_slices", k_solid_slices, ns ? ns : 1, 1024, lds_bm, (const u32*)c->ns_part.p,
@@ -472,13 +495,13 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
     if ((rc = count_owned(c, sbits, &ovf, &max_solid))) return rc;
     if (!ovf) break;
   }
-  if (with_pos) return solid_bits(c, (const u32*)c->singles.p, c->sing_count[0]);
+  if (with_pos) return solid_bits(c, (const u32*)c->singles.p, (const u64*)c->sing_cursor.p, c->sing_count[0]);
   return solid_build(c, rs_log2_for(max_solid));
 }
 
 int do_count(p3_ctx* c) {
   int rc;
-  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
+  if ((rc = ensure(c, c->dstats, 32 * 8))) return rc;
   const bool can_part = part_applicable(c);
   if (c->count_mode_opt == 2 && !can_part) return fail(c, P3_EBADARG, "partitioned count forced but input too large");
   if (c->count_mode_opt != 1 && can_part) {
@@ -509,7 +532,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 8, 0, 24 * 8, c->stream));
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (have_s) {
     // S was assembled by the count stage's return path
@@ -541,45 +564,57 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->P.p, c->n_words, k,
                (const u32*)c->seg_off.p, (REC*)c->kpart.p);
     u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 2 : 0);  // 16 Ki x 8 B or 4 Ki x 20 B slots
+    u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
+    const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
+                       16 * 192 * sizeof(REC);
     u32 sbits = 0;
-    while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
-    for (;; sbits++) {
-      if (sbits > 5) {
-        use_dedup = false;  // every split overflowed: fall back to the direct form below
-        break;
+    if (c->spec) {
+      sbits = c->hint_ksbits;  // no readback: overflow is checked at the end of the pass
+      HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
+      LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sbits, 1024, lds, (const REC*)c->kpart.p,
+                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, dst,
+                 (u32)c->dbg_opt);
+    } else {
+      while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
+      for (;; sbits++) {
+        if (sbits > 5) {
+          use_dedup = false;  // every split overflowed: fall back to the direct form below
+          break;
+        }
+        HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
+        LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sbits, 1024, lds, (const REC*)c->kpart.p,
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, dst,
+                   (u32)c->dbg_opt);
+        HIPCHK(c, hipMemcpyAsync(h, dst, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (h[3] == 0) break;
       }
-      const u32 nsb = P3_NB << sbits;
-      HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-      const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
-                         16 * 192 * sizeof(REC);
-      LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), nsb, 1024, lds, (const REC*)c->kpart.p,
-                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, st, (u32)c->dbg_opt);
-      HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      if (h[3] == 0) break;
     }
     if (use_dedup) {
       c->ksbits = sbits;
-      c->n_distinct_k = h[0];
+      if (!c->spec) c->n_distinct_k = h[0];
       // slices of 2^slice_log2 bits, at most 1024 of them and at most 128 KiB of LDS each
       u32 slice_log2 = 10;
       while (((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
-      const u64 n_pos = h[0] * (u64)H;
+      const u64 n_pos = c->n_distinct_k * (u64)H;  // spec: last pass's count; the scatter checks the real one
       const bool sliced = c->bloom_slices_opt && slice_log2 <= 20 && n_pos + 16ull * P3_NWG * P3_NB < (1ull << 31);
       if (sliced) {
         const u32 ns = (u32)((m + ((1ull << slice_log2) - 1)) >> slice_log2);
-        if ((rc = ensure(c, c->ppart, (n_pos + 16ull * P3_NWG * P3_NB) * 4))) return rc;
-        LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, h[0], k, mm, H,
-               slice_log2, (u32*)c->ghist.p);
+        if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+        const u64 cap_records = c->ppart.bytes / 4;
+        LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
+               mm, H, slice_log2, (u32*)c->ghist.p);
         if ((rc = do_scan(c, st + 12))) return rc;
         LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                   h[0], k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p);
+                   (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                   (const u64*)(st + 12), cap_records, st + 24);
         const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
         LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
-                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p);
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
+                   (const u64*)(st + 24));
         c->bloom_mode = 3;
       } else {
-        LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), grid_for(h[0]), 256, (const u64*)c->dkeys.p, h[0], k, mm, H,
+        LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H,
                (u32*)c->bloom.p);
         c->bloom_mode = 2;
       }
@@ -599,12 +634,27 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
          (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-  u64 hb[3];
-  HIPCHK(c, hipMemcpyAsync(hb, st + 8, sizeof hb, hipMemcpyDeviceToHost, c->stream));
+  u64 hall[32];
+  HIPCHK(c, hipMemcpyAsync(hall, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
+  if (c->spec && c->part_pos)
+    HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->bstats.n_windows_k = hb[0];
-  c->bstats.n_passing = hb[1];
-  c->bstats.n_seed_reads = hb[2];
+  if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
+  if (c->spec) {
+    // the single synchronisation point of a speculative pass: were last pass's splits still good?
+    if (hall[3] || hall[16 + 3]) return fail(c, P3_ERETRY_INTERNAL, "an LDS table overflowed under the previous split");
+    c->cstats.n_distinct = hall[0];
+    c->cstats.n_solid = hall[1];
+    c->cstats.max_count = hall[2];
+    c->cstats.n_windows = hall[5];
+    c->n_distinct_k = hall[16];
+    if (c->cstats.max_count >= (1ULL << 31))
+      return fail(c, P3_ECOUNT_OVERFLOW, "a 21-mer count (%llu) >= 2^31: reference RMQ would truncate",
+                  (unsigned long long)c->cstats.max_count);
+  }
+  c->bstats.n_windows_k = hall[8];
+  c->bstats.n_passing = hall[9];
+  c->bstats.n_seed_reads = hall[10];
   c->k = k;
   c->m = m;
   c->H = H;
@@ -736,6 +786,12 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   return P3_OK;
 }
 
+int p3_set_profile_filter(p3_ctx* c, const char* kernel_name) {
+  if (!c) return P3_EBADARG;
+  c->profile_only = kernel_name ? kernel_name : "";
+  return P3_OK;
+}
+
 int p3_load_reads(p3_ctx* c, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len) {
   if (!c) return P3_EBADARG;
   if (!offsets || (n_reads && !bases)) return fail(c, P3_EBADARG, "null bases/offsets");
@@ -783,7 +839,7 @@ int p3_mr_count_partition(p3_ctx* c) {
   if (!part_applicable(c)) return fail(c, P3_ECAPACITY, "input too large for the partitioned count (multi-rank needs it)");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = ensure(c, c->dstats, 16 * 8))) return rc;
+  if ((rc = ensure(c, c->dstats, 32 * 8))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if ((rc = do_pack(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -911,7 +967,13 @@ int p3_mr_solid_bits(p3_ctx* c, uint64_t n_positions) {
   if (!c) return P3_EBADARG;
   if (!c->part_pos || !c->ns_recv.p) return fail(c, P3_ESTATE, "no received non-solid positions");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = solid_bits(c, (const u32*)c->ns_recv.p, n_positions);
+  int rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS);
+  if (rc) return rc;
+  // the received count goes to the (now free) last word of the cursor array: the kernels read it from there
+  u64* d_n = (u64*)c->sing_cursor.p + (P3_MAX_RANKS - 1);
+  HIPCHK(c, hipMemcpyAsync(d_n, &n_positions, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  rc = solid_bits(c, (const u32*)c->ns_recv.p, d_n, n_positions);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -1095,11 +1157,57 @@ int p3_bloom_query(p3_ctx* c, const uint64_t* keys, uint64_t n, uint8_t* out) {
 }
 
 int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
+  if (!c) return P3_EBADARG;
   int rc;
+  // Speculative pass: when the previous pass over the SAME reads and parameters succeeded, its sub-bucket
+  // splits and buffer sizes are reused and the whole pass is enqueued with ONE synchronisation at the end
+  // (overflow flags are checked there; on any surprise the pass is simply repeated the careful way).
+  const bool can_spec = c->hint_valid && c->hint_epoch == c->reads_epoch && c->hint_k == k && c->hint_m == m_bits &&
+                        c->hint_H == H && c->n_ranks == 1 && c->count_mode_opt != 1 && c->gate_mode_opt != 1 &&
+                        c->bloom_mode_opt != 1 && !c->dbg_opt;
+  if (can_spec) {
+    HIPCHK(c, hipSetDevice(c->device));
+    c->spec = true;
+    rc = P3_OK;
+    do {
+      if ((rc = ensure(c, c->dstats, 32 * 8))) break;
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+      if ((rc = do_pack(c))) break;
+      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+      if ((rc = part_local(c, true))) break;
+      if ((rc = set_rx_local(c))) break;
+      bool ovf = false;
+      u64 mx = 0;
+      if ((rc = count_owned(c, c->hint_sbits, &ovf, &mx))) break;
+      if ((rc = solid_bits(c, (const u32*)c->singles.p, (const u64*)c->sing_cursor.p, c->n_words * 32))) break;
+      HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+      rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+    } while (0);
+    c->spec = false;
+    if (rc == P3_OK) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_pack = ms;
+      if (hipEventElapsedTime(&ms, c->ev[1], c->ev[6]) == hipSuccess) c->tm.ms_count = ms;
+      if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
+      return P3_OK;
+    }
+    c->hint_valid = false;
+    if (rc != P3_ERETRY_INTERNAL) return rc;
+    (void)hipStreamSynchronize(c->stream);  // fall through to the careful path
+  }
   if ((rc = p3_count_short(c))) return rc;
   if ((rc = p3_make_bloom(c, k, m_bits, H))) return rc;
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
+  if (c->count_mode == 2 && c->gate_mode == 2 && c->bloom_mode == 3) {
+    c->hint_valid = true;
+    c->hint_epoch = c->reads_epoch;
+    c->hint_sbits = c->sbits;
+    c->hint_ksbits = c->ksbits;
+    c->hint_k = k;
+    c->hint_m = m_bits;
+    c->hint_H = H;
+  }
   return P3_OK;
 }
 

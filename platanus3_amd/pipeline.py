@@ -252,8 +252,18 @@ class Pipeline:
 
     @staticmethod
     def stage_alg_bytes(L, D, R, m):
-        """Per-read algorithmic bytes by stage; B_alg(read) = 2L + 16(L-20) + 16 D/R + m/(8R) in total.
-        count stage: one stream of the bases + instance write/read + count-table write;
-        bloom stage: second stream of the bases + Bloom vector write."""
-        stage = {"count": L + 16.0 * (L - 20) + 16.0 * D / R, "bloom": L + m / (8.0 * R)}
-        return {kname: stage[st] for kname, st in STAGE_OF.items()}
+        """Per-read ALGORITHMIC bytes credited to each kernel; they sum to SURVEY.md section 8d's
+        B_alg(read) = 2L + 16(L-20) + 16 D/R + m/(8R).  A kernel gets only the term it implements: the two streams
+        of the bases (pack; the k-mer re-encode of the Bloom stage), the write and the read of the 8-byte 21-mer
+        instances, the count-table write, the Bloom-vector write.  Kernels that exist only because of HOW the
+        path is organised (histograms, scans, dedup, probe partitioning, the gate's return path) carry 0 bytes:
+        if one of them dominated, its roofline fraction would honestly read 0."""
+        own = {
+            "k_pack": float(L),
+            "k_part_scatter": 8.0 * (L - 20), "k_part_scatter_pos": 8.0 * (L - 20),
+            "k_part_count": 8.0 * (L - 20) + 16.0 * D / R,
+            "k_count_direct": 16.0 * (L - 20) + 16.0 * D / R,
+            "k_kmer_scatter": float(L), "k_bloom_direct": float(L) + m / (8.0 * R),
+            "k_bloom_slices": m / (8.0 * R), "k_bloom_insert": m / (8.0 * R),
+        }
+        return {kname: own.get(kname, 0.0) for kname in STAGE_OF}
