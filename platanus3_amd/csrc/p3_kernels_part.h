@@ -293,9 +293,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u32 n_src, u32 rows, u32 first_pb, u32 sbits, u32 ts_log2,
                                                      u64* __restrict__ out_keys, u32* __restrict__ out_counts,
                                                      uint4* __restrict__ sb_info, u64* __restrict__ gstats,
-                                                     u32* __restrict__ tpos, uint8_t* __restrict__ tsrc,
-                                                     u32* __restrict__ singles, u64* __restrict__ sing_cursor,
-                                                     u32 dbg) {
+                                                     u64* __restrict__ tpairs, u32* __restrict__ singles,
+                                                     u64* __restrict__ sing_cursor, u32 dbg) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
   constexpr u32 VCAP = POS ? P3_VCAP_POS : P3_VALID_CAP;
   constexpr u32 QCAP = POS ? P3_WQ_CAP_POS : P3_WQ_CAP;
@@ -342,7 +341,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   const u32 lane = threadIdx.x & 63;
   const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 144);
-  const u64 tbase = (u64)sb * TS;  // this sub-bucket's window of tpos / tsrc
+  const u64 tbase = (u64)sb * TS;  // this sub-bucket's window of tpairs (at most 7/8 TS entries are used)
   u32 cur_src = 0;
   auto slow_insert = [&](REC item) {
     const u32 rem = (u32)item & rem_mask;
@@ -357,11 +356,11 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         if (__hip_atomic_load(&s_ndist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= limit) break;
         old = atomicCAS(&tkey[slot], P3_EMPTY32, rem);
         if (old == P3_EMPTY32) {
-          atomicAdd(&s_ndist, 1u);
-          if constexpr (POS) {
-            tpos[tbase + slot] = (u32)((u64)item >> 32);
-            if (n_src > 1) tsrc[tbase + slot] = (uint8_t)cur_src;
-          }
+          const u32 ticket = atomicAdd(&s_ndist, 1u);
+          // first instance of a key: (source | slot | position) appended in insertion order -- dense 8-byte
+          // stores (a per-slot array cost a 64-byte line per 4-byte write: 0.9 GB of write-back per launch)
+          if constexpr (POS)
+            tpairs[tbase + ticket] = ((u64)cur_src << 56) | ((u64)slot << 32) | (u32)((u64)item >> 32);
         }
       }
       if (old == P3_EMPTY32 || old == rem) {
@@ -451,8 +450,6 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       out_counts[base + idx] = c;
       my_solid += (c >= 2);
       my_max = c > my_max ? c : my_max;
-      if constexpr (POS)
-        if (c == 1 && n_src > 1) atomicAdd(&s_sing[tsrc[tbase + i]], 1u);
       my_single += (c == 1);
     }
   }
@@ -460,6 +457,11 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     if (n_src == 1) {
       for (int off = 32; off > 0; off >>= 1) my_single += __shfl_down(my_single, off, 64);
       if (lane == 0 && my_single) atomicAdd(&s_sing[0], my_single);
+    } else {
+      for (u32 t = threadIdx.x; t < s_ndist; t += blockDim.x) {
+        const u64 pr = tpairs[tbase + t];
+        if (tcnt[(u32)(pr >> 32) & (TS - 1)] == 1) atomicAdd(&s_sing[(u32)(pr >> 56)], 1u);
+      }
     }
   }
   if constexpr (POS) {
@@ -470,22 +472,29 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       s_sing[threadIdx.x] = 0;
     }
     __syncthreads();
+    const u32 nd = s_ndist;
     if (n_src == 1) {
-      for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {  // one LDS atomic per wave (ballot prefix)
-        const u32 i = i0 + threadIdx.x;
-        const bool one = (i < TS) && tkey[i] != P3_EMPTY32 && tcnt[i] == 1;
+      for (u32 t0 = 0; t0 < nd; t0 += blockDim.x) {  // one LDS atomic per wave (ballot prefix)
+        const u32 t = t0 + threadIdx.x;
+        u64 pr = 0;
+        bool one = false;
+        if (t < nd) {
+          pr = tpairs[tbase + t];
+          one = tcnt[(u32)(pr >> 32) & (TS - 1)] == 1;
+        }
         const unsigned long long bal = __ballot(one);
         u32 wbase = 0;
         if (lane == 0 && bal) wbase = atomicAdd(&s_sing[0], (u32)__popcll(bal));
         wbase = __shfl(wbase, 0, 64);
-        if (one) singles[roff[0] + s_singbase[0] + wbase + (u32)__popcll(bal & ((1ULL << lane) - 1))] = tpos[tbase + i];
+        if (one) singles[roff[0] + s_singbase[0] + wbase + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u32)pr;
       }
     } else {
-      for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
-        if (tkey[i] != P3_EMPTY32 && tcnt[i] == 1) {
-          const u32 src = tsrc[tbase + i];
+      for (u32 t = threadIdx.x; t < nd; t += blockDim.x) {
+        const u64 pr = tpairs[tbase + t];
+        if (tcnt[(u32)(pr >> 32) & (TS - 1)] == 1) {
+          const u32 src = (u32)(pr >> 56);
           const u32 idx = atomicAdd(&s_sing[src], 1u);
-          singles[roff[src] + s_singbase[src] + idx] = tpos[tbase + i];
+          singles[roff[src] + s_singbase[src] + idx] = (u32)pr;
         }
       }
     }

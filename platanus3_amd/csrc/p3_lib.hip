@@ -365,8 +365,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if (c->part_pos) {
-    if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 4))) return rc;
-    if (c->n_ranks > 1 && (rc = ensure(c, c->tsrc, (size_t)nsb << ts_log2))) return rc;
+    if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;  // (src|slot|pos) per first instance
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
     if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
@@ -374,14 +373,14 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->rx_part,
                (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u32*)c->tpos.p, (uint8_t*)c->tsrc.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt);
+               (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)c->rx_part,
                (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u32*)nullptr, (uint8_t*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
