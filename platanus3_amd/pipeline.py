@@ -128,12 +128,63 @@ class HipBackend:
         self.ctx.mr_or_reduce(self._bloom_ptr + dst_word * 8, self._scratch_ptr, n_words, n_src, stride_words)
 
 
+class SelfComm:
+    """world = 1: every collective degenerates to a copy."""
+    rank, world = 0, 1
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        out.copy_(inp)
+
+    def all_gather_into_tensor(self, out, inp):
+        out.copy_(inp)
+
+    def all_reduce_max(self, v):
+        return int(v)
+
+    def all_reduce_sum(self, v):
+        return int(v)
+
+
+class TorchComm:
+    """torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests)."""
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.device = torch, dist, group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        self.dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits,
+                                    group=self.group)
+
+    def all_gather_into_tensor(self, out, inp):
+        self.dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def _reduce(self, v, op):
+        t = self.torch.tensor([int(v)], dtype=self.torch.int64, device=self.device)
+        self.dist.all_reduce(t, op=op, group=self.group)
+        return int(t.item())
+
+    def all_reduce_max(self, v):
+        return self._reduce(v, self.dist.ReduceOp.MAX)
+
+    def all_reduce_sum(self, v):
+        return self._reduce(v, self.dist.ReduceOp.SUM)
+
+
 class Pipeline:
-    def __init__(self, device=0, rank=0, world=1, backend=None, group=None, force_protocol=False):
+    def __init__(self, device=0, rank=0, world=1, backend=None, group=None, force_protocol=False, comm=None):
         self.rank, self.world, self.group = rank, world, group
         self.be = backend if backend is not None else HipBackend(device)
         self.ctx = getattr(self.be, "ctx", None)
         self.protocol = world > 1 or force_protocol
+        if comm is not None:
+            self.comm = comm
+        elif world > 1:
+            self.comm = TorchComm(self.be.scalar_device(), group)
+        else:
+            self.comm = SelfComm()
         if self.protocol:
             self.be.mr_config(rank, world)
         self.timing = {}
@@ -150,15 +201,8 @@ class Pipeline:
             self.ctx.run_pass(k, m, H)
             return
         import torch
-        import torch.distributed as dist
-        be, W, g = self.be, self.world, self.group
+        be, W, cm = self.be, self.world, self.comm
         dev = be.scalar_device()
-
-        def allreduce_max(v):
-            t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
-            if W > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
-            return int(t.item())
 
         # -- count: local partition, then blobs + descriptors to the bucket owners -------------------------
         be.mr_count_partition()
@@ -167,28 +211,18 @@ class Pipeline:
         send_counts = [rec_off[d + 1] - rec_off[d] for d in range(W)]
         sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
         rcnt = torch.empty_like(sc)
-        if W > 1:
-            dist.all_to_all_single(rcnt, sc, group=g)
-        else:
-            rcnt.copy_(sc)
+        cm.all_to_all_single(rcnt, sc)
         recv_counts = [int(x) for x in rcnt.tolist()]
         rpart, rghist, rsegoff = be.mr_recv_alloc(recv_counts, rows, row_u32, W)
-        desc = rows * row_u32
-        if W > 1:
-            dist.all_to_all_single(rpart, lay["part"][rec_off[0]:rec_off[W]], output_split_sizes=recv_counts,
-                                   input_split_sizes=send_counts, group=g)
-            dist.all_to_all_single(rghist, lay["ghist"], group=g)
-            dist.all_to_all_single(rsegoff, lay["segoff"], group=g)
-        else:
-            rpart.copy_(lay["part"][rec_off[0]:rec_off[1]])
-            rghist.copy_(lay["ghist"][:desc])
-            rsegoff.copy_(lay["segoff"][:desc])
+        cm.all_to_all_single(rpart, lay["part"][rec_off[0]:rec_off[W]], recv_counts, send_counts)
+        cm.all_to_all_single(rghist, lay["ghist"])
+        cm.all_to_all_single(rsegoff, lay["segoff"])
         self._sync(dev)
         # -- owners count; the sub-bucket split grows in lockstep if any LDS table overflowed ---------------
-        sbits = allreduce_max(be.mr_initial_sbits())
+        sbits = cm.all_reduce_max(be.mr_initial_sbits())
         while True:
             ovf, max_solid = be.mr_count_owned(sbits)
-            if not allreduce_max(ovf):
+            if not cm.all_reduce_max(ovf):
                 break
             sbits += 1
             if sbits > 5:
@@ -199,26 +233,20 @@ class Pipeline:
             singles, offs, cnts = be.mr_singles_layout()
             sc2 = torch.tensor(cnts, dtype=torch.int64, device=dev)
             rc2 = torch.empty_like(sc2)
-            if W > 1:
-                dist.all_to_all_single(rc2, sc2, group=g)
-            else:
-                rc2.copy_(sc2)
+            cm.all_to_all_single(rc2, sc2)
             rcnts = [int(x) for x in rc2.tolist()]
             buf = be.mr_nonsolid_recv_alloc(sum(rcnts))
             send = torch.cat([singles[o:o + c] for o, c in zip(offs, cnts)]) if W > 1 else singles[offs[0]:offs[0] + cnts[0]]
-            if W > 1:
-                dist.all_to_all_single(buf, send, output_split_sizes=rcnts, input_split_sizes=cnts, group=g)
-            else:
-                buf.copy_(send)
+            cm.all_to_all_single(buf, send, rcnts, cnts)
             self._sync(dev)
             be.mr_solid_bits(sum(rcnts))
         else:
             # -- gate, table form: all-gather the owners' solid regions ----------------------------------------
-            rs_log2 = be.rs_log2_for(allreduce_max(max_solid))
+            rs_log2 = be.rs_log2_for(cm.all_reduce_max(max_solid))
             solid, off, own = be.mr_solid_build(rs_log2)
             if W > 1:
                 mine = solid[off:off + own].clone()
-                dist.all_gather_into_tensor(solid, mine, group=g)
+                cm.all_gather_into_tensor(solid, mine)
                 self._sync(dev)
         # -- Bloom: rank-local partial vector, then OR-merge ---------------------------------------------------
         be.make_bloom(k, m, H)
@@ -227,11 +255,11 @@ class Pipeline:
             n = words.numel()
             chunk = n // W
             scratch = be.mr_scratch(n)
-            dist.all_to_all_single(scratch, words, group=g)
+            cm.all_to_all_single(scratch, words)
             self._sync(dev)
             be.mr_or_reduce(self.rank * chunk, chunk, W, chunk)
             mine = words[self.rank * chunk:(self.rank + 1) * chunk].clone()
-            dist.all_gather_into_tensor(words, mine, group=g)
+            cm.all_gather_into_tensor(words, mine)
             self._sync(dev)
 
     def _sync(self, dev):
@@ -241,14 +269,7 @@ class Pipeline:
 
     # ---- results ------------------------------------------------------------------------------------------
     def global_distinct(self):
-        n = self.ctx.count_stats()["n_distinct"]
-        if self.world > 1:
-            import torch
-            import torch.distributed as dist
-            t = torch.tensor([n], dtype=torch.int64, device=self.be.scalar_device())
-            dist.all_reduce(t, group=self.group)
-            n = int(t.item())
-        return n
+        return self.comm.all_reduce_sum(self.ctx.count_stats()["n_distinct"])
 
     @staticmethod
     def stage_alg_bytes(L, D, R, m):

@@ -251,3 +251,51 @@ def test_config2_full_size_against_reference_checksums(ctx):
         for i in range(k):
             rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
         assert ctx.bloom_query(np.minimum(samp, rc)).all()
+
+
+@pytest.mark.parametrize("world,k,gate", [(2, 31, 2), (4, 31, 2), (4, 41, 1), (8, 25, 2)])
+def test_multirank_loopback(oracle, world, k, gate):
+    """The REAL multi-rank protocol (HIP kernels, n_ranks = 2/4/8) on one GPU: `world` contexts driven by threads,
+    exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads."""
+    import threading
+    from loopback_comm import LoopbackWorld
+    from platanus3_amd.pipeline import Pipeline
+    n_reads = 24000
+    per = n_reads // world
+    b, o = synth.reads(seed=41, total_reads=n_reads, read_len=150)
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    lw = LoopbackWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            bb, oo = synth.reads(seed=41, total_reads=n_reads, first_read=r * per, n_reads=per, read_len=150)
+            pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
+            pipe.ctx.set_option("gate_mode", gate)
+            pipe.load_reads(bb, oo, min_len=k)
+            pipe.run_pass(k, m, H)
+            c = pipe.ctx
+            c.k, c.m, c.H = k, m, H
+            keys, counts = c.export_counts()
+            results[r] = (keys.copy(), counts.copy(), c.export_bloom(), [capi.decode_key(x, k) for x in c.export_seeds()])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    keys = np.concatenate([r[0] for r in results])
+    counts = np.concatenate([r[1] for r in results])
+    assert np.unique(keys).size == keys.size
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], ekeys) and np.array_equal(counts[order], ecounts)
+    for r in results:
+        assert np.array_equal(r[2], ebloom)
+    assert sorted(set(s for r in results for s in r[3])) == eseeds
