@@ -451,8 +451,10 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
 }
 
 u32 initial_sbits(u64 total_windows_bound) {
-  u32 sbits = 1;  // aim at <= 64 Ki instances per LDS table
-  while (sbits < 5 && total_windows_bound / ((u64)P3_NB << sbits) > 65536) sbits++;
+  // First guess: <= 96 Ki instances per 16 Ki-slot LDS table (~7x coverage gives <= 14 Ki distinct keys).  A wrong
+  // guess only costs one repeated count launch: the overflow flag bumps the split and the next pass remembers it.
+  u32 sbits = 1;
+  while (sbits < 5 && total_windows_bound / ((u64)P3_NB << sbits) > 98304) sbits++;
   return sbits;
 }
 
