@@ -17,18 +17,18 @@
 template <typename REC, u32 VCAP = P3_VALID_CAP, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
                                                 const u32* __restrict__ ghist, u32 pb, uint8_t* valid, u32* sc2,
-                                                F f) {
+                                                F f, u32 seg_begin = 0, u32 seg_count = P3_NWG) {
   constexpr u32 RPV = 16 / sizeof(REC);  // records per 16-byte vector
   constexpr u32 VPC = 16 / RPV;          // vectors per 16-record chunk
-  // segment descriptor of thread t < NWG
+  // segment descriptor of thread t < seg_count (segments [seg_begin, seg_begin+seg_count) of row pb)
   u32 my_off = 0, my_n = 0;
-  if (threadIdx.x < P3_NWG) {
-    my_off = seg_off[pb * P3_NWG + threadIdx.x];
-    my_n = ghist[pb * P3_NWG + threadIdx.x];
+  if (threadIdx.x < seg_count) {
+    my_off = seg_off[pb * P3_NWG + seg_begin + threadIdx.x];
+    my_n = ghist[pb * P3_NWG + seg_begin + threadIdx.x];
   }
   __syncthreads();  // sc2 / valid may still be in use by a previous call
   if (threadIdx.x == 0) sc2[0] = my_off;
-  if (threadIdx.x == P3_NWG - 1) sc2[1] = my_off + ((my_n + 15u) & ~15u);
+  if (threadIdx.x == seg_count - 1) sc2[1] = my_off + ((my_n + 15u) & ~15u);
   __syncthreads();
   const u32 start = sc2[0];                    // first record of the bucket (multiple of 16)
   const u32 nch = (sc2[1] - start) >> 4;       // chunks in the bucket
@@ -36,7 +36,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
   const u32 my_nc = (my_n + 15u) >> 4;         // chunks of my segment
   for (u32 wb = 0; wb < nch; wb += VCAP) {
     const u32 wn = (nch - wb) < VCAP ? (nch - wb) : VCAP;
-    if (threadIdx.x < P3_NWG) {
+    if (threadIdx.x < seg_count) {
       // chunks [my_c0, my_c0+my_nc) intersected with [wb, wb+wn)
       u32 lo = my_c0 > wb ? my_c0 : wb;
       u32 hi = (my_c0 + my_nc) < (wb + wn) ? (my_c0 + my_nc) : (wb + wn);

@@ -290,10 +290,11 @@ template <bool POS>
 __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off,
                                                      const u32* __restrict__ ghist, const u64* __restrict__ roff,
-                                                     u32 n_src, u32 rows, u32 first_pb, u32 sbits, u32 ts_log2,
-                                                     u64* __restrict__ out_keys, u32* __restrict__ out_counts,
-                                                     uint4* __restrict__ sb_info, u64* __restrict__ gstats,
-                                                     u64* __restrict__ tpairs, u32* __restrict__ singles,
+                                                     u32 n_src, u32 rows, u32 first_pb, u32 xbits, u32 sbits,
+                                                     u32 ts_log2, u64* __restrict__ out_keys,
+                                                     u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
+                                                     u64* __restrict__ gstats, u64* __restrict__ tpairs,
+                                                     u32* __restrict__ singles,
                                                      u64* __restrict__ sing_cursor, u32 dbg) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
   constexpr u32 VCAP = POS ? P3_VCAP_POS : P3_VALID_CAP;
@@ -335,9 +336,14 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   const u32 pb_local = grp * 8u + (rr & 7u);
   const u32 subsel = rr >> 3;
   const u32 sb = pb_local * nsub + subsel;  // owned (local) sub-bucket index
-  const u32 pb = first_pb + pb_local;        // global bucket id (key reconstruction)
-  const u32 rem_bits = 32 - sbits;
+  // xbits > 0: the owner re-partitioned its received records by the next xbits of g (k_repart_*), so the row
+  // index is a CELL = (owned bucket << xbits) | those bits; the data is then one local partition whose 256
+  // segments per cell are grouped by source rank (256 / n_src consecutive segments each).
+  const u32 pb = first_pb + (pb_local >> xbits);  // global bucket id (key reconstruction)
+  const u32 xval = pb_local & ((1u << xbits) - 1);
+  const u32 rem_bits = 32 - xbits - sbits;
   const u32 rem_mask = (1u << rem_bits) - 1;  // sbits >= 1
+  const u32 sub_mask = (1u << sbits) - 1;
   const u32 lane = threadIdx.x & 63;
   const u32 limit = TS - (TS >> 3);  // refuse to run the table above 7/8 full
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 144);
@@ -380,8 +386,9 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   const unsigned long long lt_mask = (1ULL << lane) - 1;
   for (u32 src = 0; src < n_src; src++) {
     cur_src = src;
-    const u32 row = src * rows + pb_local;
-    const REC* part_src = part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
+    const u32 row = xbits ? pb_local : src * rows + pb_local;
+    const REC* part_src = xbits ? part : part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
+    const u32 segs = xbits ? P3_NWG / n_src : P3_NWG;
     bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
       if (dbg & 2) {  // timing experiment: read only
         u64 x = 0;
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
 #pragma unroll
         for (int t = 0; t < G; t++) {
           const int i = g0 + t;
-          const bool mine = (act & (1u << i)) && (((u32)r[i] >> rem_bits) == subsel);
+          const bool mine = (act & (1u << i)) && ((((u32)r[i] >> rem_bits) & sub_mask) == subsel);
           const bool hit = mine && cur[t] == rem[t];
           if (hit) atomicAdd(&tcnt[slot[t]], 1u);
           const bool miss = mine && !hit;
@@ -417,7 +424,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           slow_insert(wq[qn + lane]);
         }
       }
-    });
+    }, xbits ? src * segs : 0u, segs);
     // the queue is emptied before the next source so that a first insertion is credited to the right rank
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (lane < qn) slow_insert(wq[lane]);
@@ -445,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     if (full) {
       const u32 c = tcnt[i];
       const u32 idx = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
-      const u64 g = ((u64)pb << 32) | ((u64)subsel << rem_bits) | rem;
+      const u64 g = ((u64)pb << 32) | (xbits ? ((u64)xval << (32 - xbits)) : 0ULL) | ((u64)subsel << rem_bits) | rem;
       out_keys[base + idx] = unmix42(g);
       out_counts[base + idx] = c;
       my_solid += (c >= 2);

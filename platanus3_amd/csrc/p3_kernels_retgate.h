@@ -203,3 +203,76 @@ __global__ void __launch_bounds__(1024) k_solid_slices(const u32* __restrict__ p
     }
   }
 }
+
+// ---- owner-side re-partition (multi-rank) -------------------------------------------------------------------------
+// With N ranks an owner receives only 1024/N buckets, each N times larger than in the single-rank case; counting
+// them directly would need N times more sub-bucket passes over every bucket.  Instead the received records are
+// split once more by the next log2(N) bits of g into 1024 local CELLS (cell = owned bucket << xbits | bits), so
+// the count kernel sees the same cell sizes as a single rank does.  Workgroup w handles the four consecutive
+// (source, bucket) pairs 4w..4w+3 -- all from ONE source because 1024/N is a multiple of 4 -- so segment w of
+// every cell is single-source, which is how the count kernel still knows whose read a position indexes.
+template <typename REC>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_repart_hist(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
+                                                                 const u32* __restrict__ rx_ghist,
+                                                                 const u64* __restrict__ roff, u32 rows, u32 xbits,
+                                                                 u32* __restrict__ ghist) {
+  extern __shared__ __align__(16) u32 lds[];
+  u32* hist = lds;             // P3_NB
+  u32* sc = lds + P3_NB;       // 16
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  constexpr int NBATCH = 4 * (16 / sizeof(REC));
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (u32 p = blockIdx.x * 4; p < blockIdx.x * 4 + 4; p++) {
+    const u32 src = p / rows, row_local = p % rows;
+    const REC* part_src = rx + roff[src] - rx_segoff[(u64)src * rows * P3_NWG];
+    bucket_for_each<REC, P3_VCAP_POS>(part_src, rx_segoff, rx_ghist, p, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+#pragma unroll
+      for (int i = 0; i < NBATCH; i++)
+        if (act & (1u << i)) atomicAdd(&hist[(row_local << xbits) | ((u32)r[i] >> (32 - xbits))], 1u);
+    });
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
+}
+
+// Scatter side of the re-partition.  A (source, bucket) pair feeds only 2^xbits cells, so the 1024-row LDS
+// stager (built for records that spread over all rows) would overflow two rows per round; instead every wave
+// ranks its records per cell with ballots and writes each cell's run contiguously at an LDS-held cursor
+// (exact offsets from k_repart_hist + scan, so no global atomics either).
+template <typename REC>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
+                                                                    const u32* __restrict__ rx_ghist,
+                                                                    const u64* __restrict__ roff, u32 rows, u32 xbits,
+                                                                    const u32* __restrict__ seg_off, REC* __restrict__ out) {
+  constexpr int NBATCH = 4 * (16 / sizeof(REC));
+  extern __shared__ __align__(16) u32 lds[];
+  u32* cur = lds;          // P3_NB write cursors (record index into `out`), only this block's cells are used
+  u32* sc = lds + P3_NB;   // 16
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) cur[i] = seg_off[i * P3_NWG + blockIdx.x];
+  __syncthreads();
+  const u32 lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ULL << lane) - 1;
+  const u32 ncell = 1u << xbits;
+  for (u32 p = blockIdx.x * 4; p < blockIdx.x * 4 + 4; p++) {
+    const u32 src = p / rows, row_local = p % rows;
+    const REC* part_src = rx + roff[src] - rx_segoff[(u64)src * rows * P3_NWG];
+    bucket_for_each<REC, P3_VCAP_POS>(part_src, rx_segoff, rx_ghist, p, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+#pragma unroll
+      for (int i = 0; i < NBATCH; i++) {
+        const bool on = act & (1u << i);
+        const u32 xv = (u32)r[i] >> (32 - xbits);
+        for (u32 x = 0; x < ncell; x++) {  // wave-uniform loop over the few target cells
+          const bool mine = on && xv == x;
+          const unsigned long long bal = __ballot(mine);
+          if (bal == 0) continue;
+          u32 base = 0;
+          if (lane == (u32)__ffsll((long long)bal) - 1) base = atomicAdd(&cur[(row_local << xbits) | x], (u32)__popcll(bal));
+          base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+          if (mine) out[base + (u32)__popcll(bal & lt_mask)] = r[i];
+        }
+      }
+    });
+  }
+}

@@ -69,7 +69,8 @@ struct p3_ctx {
   int bloom_mode = 0;
   int tsk_log2_opt = 14;
   int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
-  u32 ksbits = 0;
+  u32 ksbits = 0, ksbits_k = 0;
+  u64 ksbits_epoch = ~0ull;
   DevBuf kpart, dkeys, ppart, scan_tmp;
   // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
   u32 rank = 0, n_ranks = 1;
@@ -77,6 +78,9 @@ struct p3_ctx {
   void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
   u64 rx_records = 0;
   bool mr_partitioned = false;
+  bool reparted = false;  // the received records have been split into 1024 local cells (n_ranks > 1)
+  u32 xbits = 0;
+  DevBuf lpart;
   // coverage gate: 1 = probe the solid-key regions per window, 2 = return path (non-solid positions come back
   // from the count stage and S is assembled without any table probe)
   int gate_mode_opt = 0, gate_mode = 1;
@@ -351,11 +355,41 @@ int part_local(p3_ctx* c, bool with_pos) {
   return P3_OK;
 }
 
+// (1b) multi-rank: split the received records into 1024 local cells by the next log2(n_ranks) bits of g
+template <typename REC>
+int repartition_rx(p3_ctx* c) {
+  int rc;
+  const u32 rows = P3_NB / c->n_ranks;
+  u32 xbits = 0;
+  while ((1u << xbits) < c->n_ranks) xbits++;
+  c->xbits = xbits;
+  if ((rc = ensure(c, c->lpart, (c->rx_records + 16ull * P3_NWG * P3_NB) * sizeof(REC)))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  const size_t lds_h = ((size_t)P3_NB + 16) * 4 + P3_VCAP_POS;
+  LAUNCH_LDS(c, "k_repart_hist", (k_repart_hist<REC>), P3_NWG, P3_PART_THREADS, lds_h, (const REC*)c->rx_part,
+             (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, rows, xbits,
+             (u32*)c->ghist.p);
+  if ((rc = do_scan(c, st + 12))) return rc;
+  const size_t lds_s = ((size_t)P3_NB + 16) * 4 + P3_VCAP_POS;
+  LAUNCH_LDS(c, "k_repart_scatter", (k_repart_scatter<REC>), P3_NWG, P3_PART_THREADS, lds_s, (const REC*)c->rx_part,
+             (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, rows, xbits,
+             (const u32*)c->seg_off.p, (REC*)c->lpart.p);
+  c->reparted = true;
+  return P3_OK;
+}
+
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
+  if (c->n_ranks > 1 && !c->reparted) {
+    if ((rc = c->part_pos ? repartition_rx<u64>(c) : repartition_rx<u32>(c))) return rc;
+  }
+  const u32 xbits = c->n_ranks > 1 ? c->xbits : 0;
   const u32 rows = P3_NB / c->n_ranks;
-  const u32 nsb = rows << sbits;
+  const u32 nsb = (xbits ? P3_NB : rows) << sbits;
+  const void* kpart = xbits ? c->lpart.p : c->rx_part;
+  const void* kseg = xbits ? c->seg_off.p : c->rx_segoff;
+  const void* khist = xbits ? c->ghist.p : c->rx_ghist;
   // worst case one entry per received record
   u64 maxd = c->rx_records + 1;
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
@@ -370,16 +404,16 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
-    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->rx_part,
-               (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
-               c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)kpart,
+               (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+               c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
-    LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)c->rx_part,
-               (const u32*)c->rx_segoff, (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
-               c->rank * rows, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
+               (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+               c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
   }
   c->sbits = sbits;
@@ -405,14 +439,15 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
 // (3) solid regions of the owned sub-buckets, written in place into the full-size table
 int solid_build(p3_ctx* c, u32 rs_log2) {
   int rc;
-  const u32 rows = P3_NB / c->n_ranks;
-  const u32 nsb_owned = rows << c->sbits;
-  const u32 nsb_all = P3_NB << c->sbits;
+  // sub-bucket id of a key = top (10 + xbits + sbits) bits of g (xbits > 0 only after a multi-rank re-partition)
+  const u32 eff = (c->n_ranks > 1 ? c->xbits : 0) + c->sbits;
+  const u32 nsb_all = P3_NB << eff;
+  const u32 nsb_owned = nsb_all / c->n_ranks;
   c->rs_log2 = rs_log2;
   if ((rc = ensure(c, c->solid, ((size_t)nsb_all << rs_log2) * 4))) return rc;
   const size_t lds = ((size_t)1 << rs_log2) * 4;
   LAUNCH_LDS(c, "k_solid_regions", k_solid_regions, nsb_owned, 256, lds, (const u64*)c->ckeys.p,
-             (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, c->rank * nsb_owned, c->sbits, rs_log2,
+             (const u32*)c->ccounts.p, (const uint4*)c->sb_info.p, c->rank * nsb_owned, eff, rs_log2,
              (u32*)c->solid.p);
   c->count_mode = 2;
   c->gate_mode = 1;
@@ -474,6 +509,7 @@ int set_rx_local(p3_ctx* c) {
   c->rx_ghist = c->ghist.p;
   c->rx_segoff = c->seg_off.p;
   c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+  c->reparted = false;
   return P3_OK;
 }
 
@@ -539,7 +575,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     // S was assembled by the count stage's return path
   } else if (c->count_mode == 2) {
     LAUNCH(c, "k_gate_regions", k_gate_regions, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-           (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p, c->sbits, c->rs_log2, (u32*)c->S.p);
+           (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p,
+           (c->n_ranks > 1 ? c->xbits : 0) + c->sbits, c->rs_log2, (u32*)c->S.p);
   } else {
     LAUNCH(c, "k_gate_direct", k_gate_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
            (const u32*)c->endm.p, c->n_words, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p, c->cap - 1,
@@ -577,6 +614,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                  (u32)c->dbg_opt);
     } else {
       while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
+      // the split that worked for the previous pass over the same reads and k is the best first guess
+      if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k && c->ksbits > sbits && c->ksbits <= 5) sbits = c->ksbits;
       for (;; sbits++) {
         if (sbits > 5) {
           use_dedup = false;  // every split overflowed: fall back to the direct form below
@@ -593,6 +632,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     }
     if (use_dedup) {
       c->ksbits = sbits;
+      c->ksbits_epoch = c->reads_epoch;
+      c->ksbits_k = k;
       if (!c->spec) c->n_distinct_k = h[0];
       // slices of 2^slice_log2 bits, at most 1024 of them and at most 128 KiB of LDS each
       u32 slice_log2 = 10;
@@ -727,7 +768,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->tcounts, &c->ckeys, &c->ccounts, &c->dstats, &c->bloom, &c->seeds, &c->seed_valid,
                     &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart, &c->rx_roff, &c->rx_part_buf, &c->rx_ghist_buf, &c->rx_segoff_buf,
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
-                    &c->ns_part};
+                    &c->ns_part, &c->lpart};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -897,6 +938,7 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
   c->rx_ghist = c->rx_ghist_buf.p;
   c->rx_segoff = c->rx_segoff_buf.p;
   c->rx_records = roff[c->n_ranks];
+  c->reparted = false;
   *d_rpart = c->rx_part;
   *d_rghist = c->rx_ghist;
   *d_rsegoff = c->rx_segoff;
@@ -905,7 +947,8 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
 
 int p3_mr_initial_sbits(p3_ctx* c, uint32_t* sbits) {
   if (!c || !sbits) return P3_EBADARG;
-  *sbits = initial_sbits(c->n_words * 32 * (u64)c->n_ranks);
+  // after the owner-side re-partition a cell holds 1/1024 of what this rank RECEIVED
+  *sbits = initial_sbits(c->rx_records ? c->rx_records : c->n_words * 32);
   return P3_OK;
 }
 
@@ -932,7 +975,7 @@ int p3_mr_solid_build(p3_ctx* c, uint32_t rs_log2, void** d_solid, uint64_t* own
   int rc = solid_build(c, rs_log2);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  const u64 nsb_owned = (u64)(P3_NB / c->n_ranks) << c->sbits;
+  const u64 nsb_owned = ((u64)P3_NB << ((c->n_ranks > 1 ? c->xbits : 0) + c->sbits)) / c->n_ranks;
   *d_solid = c->solid.p;
   *owned_bytes = (nsb_owned << rs_log2) * 4;
   *owned_offset_bytes = c->rank * *owned_bytes;
