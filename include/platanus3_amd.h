@@ -66,6 +66,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "gate_mode"   0 = auto (return path when the input fits), 1 = probe the solid-key regions once per window,
  *                 2 = return path: partition records carry window positions and the count stage hands back the
  *                 positions of the non-solid windows (no table probes)
+ *   "part_sizing" 0 = auto (single rank: every partition segment gets an estimated capacity, mean + 6 sigma, at a
+ *                 fixed stride -- no histogram pass / scan; an overflow (skewed keys) repeats the stage exactly),
+ *                 1 = always exact (histogram + scan)
  *   "bloom_mode"  0 = auto (dedup form when the input fits), 1 = direct (H probes per passing window),
  *                 2 = dedup (H probes per distinct passing k-mer; error if it cannot be used)
  *   "bloom_slices" 1 (default) = after dedup, probe positions are partitioned by bit-vector slice and OR-ed

@@ -36,6 +36,9 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
   const u32 my_nc = (my_n + 15u) >> 4;         // chunks of my segment
   for (u32 wb = 0; wb < nch; wb += VCAP) {
     const u32 wn = (nch - wb) < VCAP ? (nch - wb) : VCAP;
+    // segments need not abut (estimated-capacity partitions leave gaps): unmarked chunks hold no records
+    for (u32 i = threadIdx.x; i < (wn + 3) / 4; i += blockDim.x) reinterpret_cast<u32*>(valid)[i] = 0;
+    __syncthreads();
     if (threadIdx.x < seg_count) {
       // chunks [my_c0, my_c0+my_nc) intersected with [wb, wb+wn)
       u32 lo = my_c0 > wb ? my_c0 : wb;
@@ -56,16 +59,20 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       const u32 j0 = jb + threadIdx.x;
       uint4 v[4];
       u32 jj[4];
+      u32 nval[4];
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         jj[u] = j0 + u * B;
-        v[u] = (jj[u] < nvec) ? vec[jj[u]] : make_uint4(0, 0, 0, 0);
+        // a vector is fetched only if its chunk holds a record at or beyond the vector's first slot (gaps between
+        // estimated-capacity segments and segment tails cost no memory traffic)
+        nval[u] = (jj[u] < nvec) ? (u32)valid[jj[u] / VPC] : 0u;
+        v[u] = (nval[u] > (jj[u] % VPC) * RPV) ? vec[jj[u]] : make_uint4(0, 0, 0, 0);
       }
       REC recs[4 * RPV];
       u32 act = 0;
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
-        const u32 nvalid = (jj[u] < nvec) ? (u32)valid[jj[u] / VPC] : 0u;
+        const u32 nvalid = nval[u];
         const u32 first = (jj[u] % VPC) * RPV;
         if constexpr (sizeof(REC) == 4) {
           recs[4 * u + 0] = v[u].x;

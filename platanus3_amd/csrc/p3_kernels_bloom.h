@@ -41,10 +41,21 @@ __device__ __forceinline__ u64 khash(u64 lo, u64 hi) {
   return NW == 1 ? mix64(lo ^ 0x9E3779B97F4A7C15ULL) : mix64(lo ^ mix64(hi ^ 0x9E3779B97F4A7C15ULL));
 }
 
+// Segment sizing.  Exact mode (segcap == 0): a histogram pass + scan gave every (bucket, workgroup) segment its
+// exact offset.  Estimated mode (segcap > 0): keys are hash-distributed, so every segment simply gets the same
+// capacity (mean + 6 sigma + slack, a multiple of 16 records) at a fixed stride -- no histogram pass, no scan;
+// the scatter kernel reports the exact per-segment counts it wrote (ghist_out) and raises *ovf if a segment did
+// not fit (skewed input), in which case the host repeats the stage in exact mode.
+struct EstSeg {
+  u32 segcap;
+  u32* ghist_out;
+  u64* ovf;
+};
+
 // ---- generic LDS stager: rows of 128 bytes (2 chunks), flushed by 4 lanes per bucket ----------------------
 template <typename REC>
 __device__ __forceinline__ void stage_flush(uint4* stage16, u32* cnt, u32* wpos, const u32* segb, REC* __restrict__ out,
-                                            bool final_flush) {
+                                            bool final_flush, const EstSeg est = EstSeg{0, nullptr, nullptr}) {
   constexpr u32 CHUNK = Stg<REC>::CHUNK, CAP = Stg<REC>::CAP;
   const u32 q = threadIdx.x & 3;
   for (u32 it = 0; it < P3_NB / (P3_PART_THREADS / 4); it++) {
@@ -54,10 +65,15 @@ __device__ __forceinline__ void stage_flush(uint4* stage16, u32* cnt, u32* wpos,
     u32 nfl = (n / CHUNK) * CHUNK;
     if (final_flush && (n % CHUNK)) nfl += CHUNK;
     if (nfl) {
-      uint4* dst = reinterpret_cast<uint4*>(out + segb[b] + wpos[b]);
-      dst[q] = stage16[b * 8 + q];
-      if (nfl == 2 * CHUNK) dst[4 + q] = stage16[b * 8 + 4 + q];
+      if (est.segcap && wpos[b] + nfl > est.segcap) {
+        if (q == 0) *est.ovf = 1;  // segment full: results are void, the host re-runs with exact offsets
+      } else {
+        uint4* dst = reinterpret_cast<uint4*>(out + segb[b] + wpos[b]);
+        dst[q] = stage16[b * 8 + q];
+        if (nfl == 2 * CHUNK) dst[4 + q] = stage16[b * 8 + 4 + q];
+      }
     }
+    if (final_flush && est.segcap && q == 0) est.ghist_out[b * P3_NWG + blockIdx.x] = wpos[b] + n;
     if (!final_flush) {
       const u32 r = n - nfl;  // < CHUNK records stay and move to the row start (source is in a later chunk)
       if (nfl) {
@@ -144,11 +160,19 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
 }
 
 // ---- k_kmer_scatter -----------------------------------------------------------------------------------------
-template <int NW>
+__device__ __forceinline__ u32 seg_base(const u32* __restrict__ seg_off, u32 bucket, const EstSeg& est) {
+  return est.segcap ? (bucket * P3_NWG + blockIdx.x) * est.segcap : seg_off[bucket * P3_NWG + blockIdx.x];
+}
+
+// FROM_S = false: the pass bitmap P was produced by k_kmer_hist (exact mode).  FROM_S = true (estimated mode, no
+// histogram pass): the windowed AND of S is evaluated here, P is written and the two statistics are accumulated.
+template <int NW, bool FROM_S>
 __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
-                                                                  const u32* __restrict__ endm, const u32* __restrict__ P,
-                                                                  u64 n_words, u32 k, const u32* __restrict__ seg_off,
-                                                                  typename KRec<NW>::type* __restrict__ part) {
+                                                                  const u32* __restrict__ endm, u32* __restrict__ P,
+                                                                  const u32* __restrict__ S, u64 n_words, u32 k,
+                                                                  const u32* __restrict__ seg_off,
+                                                                  typename KRec<NW>::type* __restrict__ part,
+                                                                  EstSeg est, u64* __restrict__ stats) {
   typedef typename KRec<NW>::type REC;
   constexpr u32 CAP = Stg<REC>::CAP;
   constexpr int RW = (NW == 1) ? 4 : 2;  // windows per lane per round: inflow/bucket stays well below CAP
@@ -160,18 +184,36 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
     cnt[i] = 0;
     wpos[i] = 0;
-    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+    segb[i] = seg_base(seg_off, i, est);
   }
   __syncthreads();
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
+  u32 n_valid = 0, n_pass = 0;
   for (u64 base = begin; base < end; base += blockDim.x) {
     const u64 w = base + threadIdx.x;
     const bool active = w < end;
     KmerRoll<NW> kr;
     u32 pbits = 0;
     if (active) {
-      pbits = P[w];
+      if constexpr (FROM_S) {
+        // pass(p) = window [p,p+k) inside one read AND solid bits p..p+k-21 all set (== RMQ >= 2)
+        u64 Elo = (u64)endm[w] | ((u64)endm[w + 1] << 32), Ehi = (u64)endm[w + 2] | ((u64)endm[w + 3] << 32);
+        u64 Slo = (u64)S[w] | ((u64)S[w + 1] << 32), Shi = (u64)S[w + 2] | ((u64)S[w + 3] << 32);
+        const u64 vmask = (1ULL << (k - 1)) - 1, smask = (1ULL << (k - 20)) - 1;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) {
+          const bool valid = (Elo & vmask) == 0;
+          n_valid += valid;
+          if (valid && ((~Slo & smask) == 0)) pbits |= 1u << j;
+          shr128(Elo, Ehi);
+          shr128(Slo, Shi);
+        }
+        n_pass += __popc(pbits);
+        P[w] = pbits;
+      } else {
+        pbits = P[w];
+      }
       kr.init(k, fw[w], fw[w + 1], fw[w + 2], rcw[w], rcw[w + 1], rcw[w + 2]);
     }
     // a whole block with no passing window skips the rounds (uniform decision)
@@ -210,12 +252,30 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
           }
         }
         __syncthreads();
-        stage_flush<REC>(stage16, cnt, wpos, segb, part, false);
+        stage_flush<REC>(stage16, cnt, wpos, segb, part, false, est);
         more = __syncthreads_or(pend != 0);
       } while (more);
     }
   }
-  stage_flush<REC>(stage16, cnt, wpos, segb, part, true);
+  stage_flush<REC>(stage16, cnt, wpos, segb, part, true, est);
+  if constexpr (FROM_S) {
+    __syncthreads();
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;  // the stage is drained: reuse two words for the block totals
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+      n_valid += __shfl_down(n_valid, off, 64);
+      n_pass += __shfl_down(n_pass, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&cnt[0], n_valid);
+      atomicAdd(&cnt[1], n_pass);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (cnt[0]) atomicAdd((unsigned long long*)&stats[0], (unsigned long long)cnt[0]);
+      if (cnt[1]) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)cnt[1]);
+    }
+  }
 }
 
 // ---- k_kmer_dedup ---------------------------------------------------------------------------------------------
@@ -484,8 +544,8 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
                                                                  u32 k, ModM mm, u32 H, u32 slice_log2,
                                                                  const u32* __restrict__ seg_off, u32* __restrict__ out,
                                                                  const u64* __restrict__ totals, u64 cap,
-                                                                 u64* __restrict__ cap_flag) {
-  if (totals[1] > cap) {
+                                                                 u64* __restrict__ cap_flag, EstSeg est) {
+  if (!est.segcap && totals[1] > cap) {  // exact mode: the padded total must fit the buffer
     if (blockIdx.x == 0 && threadIdx.x == 0) *cap_flag = 1;
     return;
   }
@@ -501,7 +561,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
     cnt[i] = 0;
     wpos[i] = 0;
-    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+    segb[i] = seg_base(seg_off, i, est);
   }
   __syncthreads();
   u64 begin, end;
@@ -544,12 +604,12 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
           }
         }
         __syncthreads();
-        stage_flush<u32>(stage16, cnt, wpos, segb, out, false);
+        stage_flush<u32>(stage16, cnt, wpos, segb, out, false, est);
         more = __syncthreads_or(pend != 0);
       } while (more);
     }
   }
-  stage_flush<u32>(stage16, cnt, wpos, segb, out, true);
+  stage_flush<u32>(stage16, cnt, wpos, segb, out, true, est);
 }
 
 // one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else

@@ -15,11 +15,17 @@
 #pragma once
 #include "p3_kernels_bloom.h"
 
+// seg_off for the readers in estimated mode: fixed stride, no histogram / scan
+__global__ void __launch_bounds__(256) k_fixed_segoff(u32* __restrict__ seg_off, u32 segcap) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < P3_NB * P3_NWG) seg_off[i] = i * segcap;
+}
+
 // ---- k_part_scatter_pos: as k_part_scatter, records = (position << 32) | low 32 bits of g -----------------------
 __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                       const u32* __restrict__ endm, u64 n_words,
                                                                       const u32* __restrict__ seg_off,
-                                                                      u64* __restrict__ part) {
+                                                                      u64* __restrict__ part, EstSeg est) {
   constexpr u32 CAP = Stg<u64>::CAP;
   constexpr int RW = 4;
   extern __shared__ __align__(16) u32 lds[];
@@ -30,7 +36,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
     cnt[i] = 0;
     wpos[i] = 0;
-    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+    segb[i] = seg_base(seg_off, i, est);
   }
   __syncthreads();
   u64 begin, end;
@@ -82,12 +88,12 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
           }
         }
         __syncthreads();
-        stage_flush<u64>(stage16, cnt, wpos, segb, part, false);
+        stage_flush<u64>(stage16, cnt, wpos, segb, part, false, est);
         more = __syncthreads_or(pend != 0);
       } while (more);
     }
   }
-  stage_flush<u64>(stage16, cnt, wpos, segb, part, true);
+  stage_flush<u64>(stage16, cnt, wpos, segb, part, true, est);
 }
 
 // ---- generic partition of plain u32 values by (v >> shift): histogram + scatter of (v & mask) ---------------------
@@ -116,7 +122,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restr
 
 __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
                                                                  u32 shift, const u32* __restrict__ seg_off,
-                                                                 u32* __restrict__ out) {
+                                                                 u32* __restrict__ out, EstSeg est) {
   const u64 n = *n_ptr;
   constexpr u32 CAP = Stg<u32>::CAP;
   constexpr u32 VR = 4;  // values per lane per round
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
     cnt[i] = 0;
     wpos[i] = 0;
-    segb[i] = seg_off[i * P3_NWG + blockIdx.x];
+    segb[i] = seg_base(seg_off, i, est);
   }
   __syncthreads();
   u64 begin, end;
@@ -163,11 +169,11 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
         }
       }
       __syncthreads();
-      stage_flush<u32>(stage16, cnt, wpos, segb, out, false);
+      stage_flush<u32>(stage16, cnt, wpos, segb, out, false, est);
       more = __syncthreads_or(pend != 0);
     } while (more);
   }
-  stage_flush<u32>(stage16, cnt, wpos, segb, out, true);
+  stage_flush<u32>(stage16, cnt, wpos, segb, out, true, est);
 }
 
 // ---- k_solid_slices: S[w] = valid21 bits of word w AND NOT the non-solid bits of this slice --------------------------
@@ -276,3 +282,17 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* _
     });
   }
 }
+
+// sum of a u32 array into *out (valid-window total when no histogram scan produced it)
+__global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 n, u64* __restrict__ out) {
+  __shared__ unsigned long long blk;
+  if (threadIdx.x == 0) blk = 0;
+  __syncthreads();
+  u64 acc = 0;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc += v[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&blk, (unsigned long long)acc);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk) atomicAdd((unsigned long long*)out, blk);
+}
+

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -47,6 +48,7 @@ struct p3_ctx {
   const u64* d_offsets = nullptr;
   DevBuf owned_bases, owned_offsets;
   u64 n_reads = 0, n_bases = 0, n_words = 0;
+  u64 host_windows = 0;  // sum over admitted reads of (L - 20), when the offsets were seen on the host (else 0)
   u32 min_len = 0;
   bool have_reads = false;
 
@@ -68,7 +70,9 @@ struct p3_ctx {
   int bloom_mode_opt = 0;   // 0 auto, 1 direct (one insert per window), 2 dedup (one insert per distinct k-mer)
   int bloom_mode = 0;
   int tsk_log2_opt = 14;
-  int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
+  int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)
+  int sizing_opt = 0;       // 0 auto (estimated segment capacities on one rank), 1 exact (histogram + scan)
+  bool est_ok = true;       // cleared when an estimated segment overflowed (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0, ksbits_k = 0;
   u64 ksbits_epoch = ~0ull;
   DevBuf kpart, dkeys, ppart, scan_tmp;
@@ -78,6 +82,7 @@ struct p3_ctx {
   void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
   u64 rx_records = 0;
   bool mr_partitioned = false;
+  bool protocol = false;  // p3_mr_config was called: blobs must be contiguous, so segment offsets stay exact
   bool reparted = false;  // the received records have been split into 1024 local cells (n_ranks > 1)
   u32 xbits = 0;
   DevBuf lpart;
@@ -85,12 +90,16 @@ struct p3_ctx {
   // from the count stage and S is assembled without any table probe)
   int gate_mode_opt = 0, gate_mode = 1;
   bool part_pos = false;  // the current partition carries positions (8-byte records)
+  bool part_est = false;  // ... and was laid out with estimated segment capacities
   DevBuf part8, tpos, tsrc, singles, sing_cursor, ns_recv, ns_part;
   u64 sing_count[P3_MAX_RANKS] = {0};
   bool s_ready = false;
   // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
   bool spec = false, hint_valid = false;
   u32 hint_sbits = 1, hint_ksbits = 0, hint_k = 0, hint_H = 0;
+  u64 hint_nsing = 0;
+  u32 pass_hint_k = 0;
+  u64 pass_hint = 0;  // passing k-mer windows of the previous Bloom build over these reads with the same k
   u64 hint_m = 0, reads_epoch = 0, hint_epoch = 0;
   int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
@@ -252,6 +261,9 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->packed = c->counted = c->bloomed = false;
   c->reads_epoch++;
   c->hint_valid = false;
+  c->est_ok = true;
+  c->host_windows = 0;
+  c->pass_hint = 0;
   return P3_OK;
 }
 
@@ -310,6 +322,26 @@ int do_count_direct(p3_ctx* c) {
 // limits of the partitioned form: 32-bit record indices
 bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG * P3_NB < (1ull << 31); }
 
+// Estimated-capacity segments (single rank): capacity = mean + 6 sigma + slack records, multiple of 16
+u32 segcap_for(double mean) {
+  const double c = mean + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) + 32.0;
+  return ((u32)c + 15u) & ~15u;
+}
+
+bool est_mode(const p3_ctx* c) { return c->n_ranks == 1 && !c->protocol && c->est_ok && c->sizing_opt != 1; }
+
+// records one workgroup of the hist/scatter kernels can emit at most (its share of the stream words x 32)
+u64 wg_window_bound(const p3_ctx* c) {
+  u64 per = (c->n_words + P3_NWG - 1) / P3_NWG;
+  per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+  return per * 32;
+}
+
+int fixed_segoff(p3_ctx* c, u32 segcap) {
+  LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off.p, segcap);
+  return P3_OK;
+}
+
 // exact segment offsets from the (bucket, workgroup) histogram; totals -> st_totals[0..2]
 int do_scan(p3_ctx* c, u64* st_totals) {
   int rc;
@@ -328,29 +360,46 @@ bool retgate_applicable(const p3_ctx* c) { return part_applicable(c) && c->n_wor
 int part_local(p3_ctx* c, bool with_pos) {
   int rc;
   const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+  const bool est = with_pos && est_mode(c);
+  // mean records per (bucket, workgroup) segment: exact window count when the host saw the offsets, else the
+  // stream-word bound
+  const double mean21 = c->host_windows ? (double)c->host_windows * 1.02 / ((double)P3_NB * P3_NWG)
+                                        : (double)wg_window_bound(c) / P3_NB;
+  const u32 segcap = est ? segcap_for(mean21) : 0;
   if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
   if (with_pos) {
-    if ((rc = ensure(c, c->part8, max_records * 8))) return rc;
+    if ((rc = ensure(c, c->part8, (est ? (u64)P3_NB * P3_NWG * segcap : max_records) * 8))) return rc;
   } else {
     if ((rc = ensure(c, c->part, max_records * 4))) return rc;
   }
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
-  LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-         (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
-  if ((rc = do_scan(c, st + 5))) return rc;  // totals at st[5..7]
-  if (with_pos) {
-    const size_t lds = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
-    LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
-               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u64*)c->part8.p);
+  const size_t lds8 = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+  if (est) {
+    // no histogram pass and no scan: fixed-stride segments; the scatter reports what it wrote
+    if ((rc = fixed_segoff(c, segcap))) return rc;
+    LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds8, (const u64*)c->fw.p,
+               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u64*)c->part8.p,
+               (EstSeg{segcap, (u32*)c->ghist.p, st + 26}));
+    LAUNCH(c, "k_sum_u32", k_sum_u32, 256, 256, (const u32*)c->ghist.p, P3_NB * P3_NWG, st + 5);
   } else {
-    const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
-    LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
-               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
+    LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
+    if ((rc = do_scan(c, st + 5))) return rc;  // totals at st[5..7]
+    if (with_pos) {
+      LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds8, (const u64*)c->fw.p,
+                 (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p,
+                 (u64*)c->part8.p, (EstSeg{0, nullptr, nullptr}));
+    } else {
+      const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
+      LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
+                 (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u32*)c->part.p);
+    }
   }
   c->part_pos = with_pos;
+  c->part_est = est;
   c->s_ready = false;
   return P3_OK;
 }
@@ -423,9 +472,13 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     *max_solid_sb = 0;
     return P3_OK;
   }
-  u64 h[8];
+  u64 h[32];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
+    c->est_ok = false;
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+  }
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
@@ -465,15 +518,28 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
   if (slice_log2 > 20) return fail(c, P3_ECAPACITY, "window bitmap too large for the return-path gate");
   const u32 ns = (u32)((n_bits + ((1ull << slice_log2) - 1)) >> slice_log2);
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
-  if ((rc = ensure(c, c->ns_part, (n_pos_bound + 16ull * P3_NWG * P3_NB) * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 12, 0, 3 * 8, c->stream));
-  LAUNCH(c, "k_u32_hist", k_u32_hist, P3_NWG, P3_PART_THREADS, d_positions, d_n_pos, slice_log2, (u32*)c->ghist.p);
-  if ((rc = do_scan(c, st + 12))) return rc;
   const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
-  LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
-             (const u32*)c->seg_off.p, (u32*)c->ns_part.p);
+  // estimated mode needs the number of positions (or last pass's) on the host to size the segments
+  const u64 n_est = c->spec ? c->hint_nsing : n_pos_bound;
+  const bool est = est_mode(c) && (c->spec ? c->hint_nsing > 0 : true);
+  if (est) {
+    u64 per = (n_est + n_est / 16 + P3_NWG - 1) / P3_NWG;
+    per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+    const u32 segcap = segcap_for((double)per / (ns ? ns : 1));
+    if ((rc = ensure(c, c->ns_part, (u64)P3_NB * P3_NWG * segcap * 4))) return rc;
+    if ((rc = fixed_segoff(c, segcap))) return rc;
+    LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
+               (const u32*)c->seg_off.p, (u32*)c->ns_part.p, (EstSeg{segcap, (u32*)c->ghist.p, st + 26}));
+  } else {
+    if ((rc = ensure(c, c->ns_part, (n_pos_bound + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+    HIPCHK(c, hipMemsetAsync(st + 12, 0, 3 * 8, c->stream));
+    LAUNCH(c, "k_u32_hist", k_u32_hist, P3_NWG, P3_PART_THREADS, d_positions, d_n_pos, slice_log2, (u32*)c->ghist.p);
+    if ((rc = do_scan(c, st + 12))) return rc;
+    LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
+               (const u32*)c->seg_off.p, (u32*)c->ns_part.p, (EstSeg{0, nullptr, nullptr}));
+  }
   const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
   LAUNCH_LDS(c, "k_solid_slices", k_solid_slices, ns ? ns : 1, 1024, lds_bm, (const u32*)c->ns_part.p,
              (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, (const u32*)c->endm.p, c->n_words,
@@ -508,7 +574,7 @@ int set_rx_local(p3_ctx* c) {
   c->rx_part = c->part_pos ? c->part8.p : c->part.p;
   c->rx_ghist = c->ghist.p;
   c->rx_segoff = c->seg_off.p;
-  c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+  c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;  // bound on real records (sizes the outputs)
   c->reparted = false;
   return P3_OK;
 }
@@ -569,7 +635,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 8, 0, 24 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (have_s) {
     // S was assembled by the count stage's return path
@@ -589,18 +655,31 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (use_dedup) {
     const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
+    const bool est = est_mode(c);
+    double mean_k = (double)wg_window_bound(c) / P3_NB;
+    if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * P3_NWG);
+    if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * P3_NWG);
+    const u32 segcap_k = est ? segcap_for(mean_k) : 0;
     if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
-    if ((rc = ensure(c, c->kpart, max_records * sizeof(REC)))) return rc;
+    if ((rc = ensure(c, c->kpart, (est ? (u64)P3_NB * P3_NWG * segcap_k : max_records) * sizeof(REC)))) return rc;
     if ((rc = ensure(c, c->dkeys, (c->n_words * 32 + 1) * 8 * NW))) return rc;
-    LAUNCH(c, "k_kmer_hist", (k_kmer_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-           (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, (u32*)c->ghist.p, (u32*)c->P.p, st + 8);
-    if ((rc = do_scan(c, st + 12))) return rc;  // totals at st[12..14]
     const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
-    LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
-               (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->P.p, c->n_words, k,
-               (const u32*)c->seg_off.p, (REC*)c->kpart.p);
+    if (est) {
+      // estimated segment capacities: the scatter evaluates the gate itself (P, statistics) -- no histogram pass
+      if ((rc = fixed_segoff(c, segcap_k))) return rc;
+      LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW, true>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
+                 (const u64*)c->rcw.p, (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k,
+                 (const u32*)c->seg_off.p, (REC*)c->kpart.p, (EstSeg{segcap_k, (u32*)c->ghist.p, st + 25}), st + 8);
+    } else {
+      LAUNCH(c, "k_kmer_hist", (k_kmer_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+             (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, (u32*)c->ghist.p, (u32*)c->P.p, st + 8);
+      if ((rc = do_scan(c, st + 12))) return rc;  // totals at st[12..14]
+      LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
+                 (const u64*)c->rcw.p, (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k,
+                 (const u32*)c->seg_off.p, (REC*)c->kpart.p, (EstSeg{0, nullptr, nullptr}), st + 8);
+    }
     u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 2 : 0);  // 16 Ki x 8 B or 4 Ki x 20 B slots
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
     const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
@@ -642,14 +721,26 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       const bool sliced = c->bloom_slices_opt && slice_log2 <= 20 && n_pos + 16ull * P3_NWG * P3_NB < (1ull << 31);
       if (sliced) {
         const u32 ns = (u32)((m + ((1ull << slice_log2) - 1)) >> slice_log2);
-        if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
-        const u64 cap_records = c->ppart.bytes / 4;
-        LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
-               mm, H, slice_log2, (u32*)c->ghist.p);
-        if ((rc = do_scan(c, st + 12))) return rc;
-        LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                   (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                   (const u64*)(st + 12), cap_records, st + 24);
+        if (est) {
+          // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
+          const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
+          const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
+          const u32 segcap_p = segcap_for((double)per_keys * H / ns);
+          if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
+          if ((rc = fixed_segoff(c, segcap_p))) return rc;
+          LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                     (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                     (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}));
+        } else {
+          if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+          const u64 cap_records = c->ppart.bytes / 4;
+          LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
+                 mm, H, slice_log2, (u32*)c->ghist.p);
+          if ((rc = do_scan(c, st + 12))) return rc;
+          LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                     (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                     (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}));
+        }
         const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
         LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
                    (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
@@ -682,6 +773,11 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
+  if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
+    c->est_ok = false;
+    c->counted = c->counted && !hall[26];
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+  }
   if (c->spec) {
     // the single synchronisation point of a speculative pass: were last pass's splits still good?
     if (hall[3] || hall[16 + 3]) return fail(c, P3_ERETRY_INTERNAL, "an LDS table overflowed under the previous split");
@@ -697,6 +793,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   c->bstats.n_windows_k = hall[8];
   c->bstats.n_passing = hall[9];
   c->bstats.n_seed_reads = hall[10];
+  c->pass_hint = hall[9];
+  c->pass_hint_k = k;
   c->k = k;
   c->m = m;
   c->H = H;
@@ -799,6 +897,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     c->bloom_mode_opt = (int)value;
   } else if (n == "bloom_slices") {
     c->bloom_slices_opt = value != 0;
+  } else if (n == "part_sizing") {
+    if (value < 0 || value > 1) return fail(c, P3_EBADARG, "part_sizing must be 0 (auto) or 1 (exact)");
+    c->sizing_opt = (int)value;
   } else if (n == "dbg") {
     c->dbg_opt = (int)value;
   } else if (n == "tsk_log2") {
@@ -850,7 +951,14 @@ int p3_load_reads(p3_ctx* c, const char* bases, const uint64_t* offsets, uint64_
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->d_bases = (const uint8_t*)c->owned_bases.p;
   c->d_offsets = (const u64*)c->owned_offsets.p;
-  return set_reads_common(c, n_reads, n_bases, min_len);
+  u64 hw = 0;
+  for (u64 i = 0; i < n_reads; i++) {
+    const u64 L = offsets[i + 1] - offsets[i];
+    if (L >= min_len && L >= P3_SHORTK) hw += L - (P3_SHORTK - 1);
+  }
+  rc = set_reads_common(c, n_reads, n_bases, min_len);
+  c->host_windows = hw;
+  return rc;
 }
 
 int p3_load_reads_device(p3_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
@@ -870,6 +978,7 @@ int p3_mr_config(p3_ctx* c, uint32_t rank, uint32_t n_ranks) {
     return fail(c, P3_EBADARG, "n_ranks must divide %u and be <= %d (got rank %u of %u)", P3_NB, P3_MAX_RANKS, rank, n_ranks);
   c->rank = rank;
   c->n_ranks = n_ranks;
+  c->protocol = true;
   c->counted = c->bloomed = false;
   c->mr_partitioned = false;
   return P3_OK;
@@ -1059,7 +1168,10 @@ int p3_count_short(p3_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if ((rc = do_pack(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  if ((rc = do_count(c))) return rc;
+  rc = do_count(c);
+  if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);  // estimated capacities overflowed: once more with exact offsets
+  if (rc == P3_ERETRY_INTERNAL) rc = fail(c, P3_EHIP, "internal retry failed");
+  if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   float ms = 0;
@@ -1117,7 +1229,19 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     return fail(c, P3_ECOUNT_OVERFLOW, "a 21-mer count (%llu) >= 2^31: reference RMQ would truncate",
                 (unsigned long long)c->cstats.max_count);
   HIPCHK(c, hipSetDevice(c->device));
-  return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+  rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+  if (rc == P3_ERETRY_INTERNAL && !c->protocol) {
+    // an estimated-capacity partition overflowed: repeat with exact offsets (the count stage too if its
+    // solid-window partition was the one that overflowed)
+    if (!c->counted) {
+      rc = do_count(c);
+      if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);
+      if (rc) return rc == P3_ERETRY_INTERNAL ? fail(c, P3_EHIP, "internal retry failed") : rc;
+    }
+    rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+  }
+  if (rc == P3_ERETRY_INTERNAL) rc = fail(c, P3_EHIP, "internal retry failed");
+  return rc;
 }
 
 int p3_get_bloom_stats(p3_ctx* c, p3_bloom_stats* out) {
@@ -1248,6 +1372,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     c->hint_epoch = c->reads_epoch;
     c->hint_sbits = c->sbits;
     c->hint_ksbits = c->ksbits;
+    c->hint_nsing = c->sing_count[0];
     c->hint_k = k;
     c->hint_m = m_bits;
     c->hint_H = H;
