@@ -159,8 +159,14 @@ def main():
             avg_ms = dom["total_ms"] / dom["launches"]
             per_launch_bytes = stage_bytes.get(dom_name, 0.0) * (args.reads)  # this rank's reads per launch
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), if this kernel is in them
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")) as f:
+                    traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+            except (OSError, ValueError, KeyError):
+                pass
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
                     "alg_bytes_per_launch": per_launch_bytes,
                     "pass_alg_bytes_per_kmer": b_alg_kmer,
                     "pass_frac": (value / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
