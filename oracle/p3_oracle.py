@@ -24,8 +24,8 @@ def nwords(k):
 def build(force=False):
     """Compile libp3oracle.so (always) and _ref/libp3ref.so (only where /root/reference exists)."""
     so = os.path.join(_HERE, "libp3oracle.so")
-    src = os.path.join(_HERE, "p3_oracle.cpp")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("p3_oracle.cpp", "p3_oracle_dbg.cpp", "p3_oracle.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libp3oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src"):
         ref = os.path.join(_HERE, "_ref", "libp3ref.so")
@@ -73,6 +73,10 @@ class Oracle:
         L.p3o_refshaped_pass.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, C.c_int,
                                          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                          C.c_void_p, C.POINTER(C.c_uint64)]
+        L.p3o_dbg.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, C.c_int, _u64p, C.c_uint64, C.c_int, _u64p, C.c_uint64,
+                              C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.p3o_free.argtypes = [C.c_void_p]
         for f in ("p3o_encode_fwd", "p3o_encode_rc"):
             getattr(L, f).argtypes = [C.c_char_p, C.c_int, _u64p]
         L.p3o_complement.argtypes = [_u64p, C.c_int, _u64p]
@@ -194,6 +198,23 @@ class Oracle:
         self.lib.p3o_bloom_query(np.ascontiguousarray(words, dtype=np.uint64), m, H,
                                  keys if keys.size else np.zeros(1, np.uint64), n, k, out)
         return out[:n].copy()
+
+    def dbg_gfa(self, reads, bloom_words, m, H, seeds, k, min_len=None):
+        """G4-G6: GFA text of the de Bruijn stage from (reads, Bloom words, seed strings)."""
+        bases, offs = _flat(reads)
+        min_len = k if min_len is None else min_len
+        nw = nwords(k)
+        sk = np.zeros(max(1, len(seeds)) * nw, np.uint64)
+        for i, sd in enumerate(seeds):
+            sk[i * nw:(i + 1) * nw] = self.encode_fwd(sd)
+        txt, ln = C.c_void_p(), C.c_uint64()
+        nj, njo, ns = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = self.lib.p3o_dbg(bases, offs, offs.size - 1, min_len, k, np.ascontiguousarray(bloom_words, np.uint64), m, H,
+                              sk, len(seeds), C.byref(txt), C.byref(ln), C.byref(nj), C.byref(njo), C.byref(ns))
+        assert rc == 0, rc
+        s = C.string_at(txt.value, ln.value).decode()
+        self.lib.p3o_free(txt)
+        return s, dict(junctions=nj.value, joints=njo.value, straights=ns.value)
 
     def refshaped_pass(self, reads, k, m, H, min_len=None, want_bloom=False):
         bases, offs = _flat(reads)

@@ -1,0 +1,307 @@
+// oracle/p3_oracle_dbg.cpp -- TEST INFRASTRUCTURE ONLY (same rules as p3_oracle.cpp).
+//
+// CPU restatement of the de Bruijn stage: node set, junction / joint /
+// straight classification, node coverage and the GFA text of reference src/DeBruijnGraph.cpp:93-544.
+// It restates WHAT the reference's seeded, order-dependent traversal produces as an order-independent
+// structure (validated against the reference's own GFA in canonical form, tests/test_oracle_vs_ref.py):
+//
+//   nodes      = closure of the seeds under Bloom-positive adjacency (MakeDBG/SearchNode/Extend*, :93-297:
+//                every reached k-mer's 4 left and 4 right neighbours are Bloom-queried in canonical form, :317-345)
+//   junction   = node whose (left degree, right degree) != (1,1), or a (1,1) node alone between two such nodes
+//                (:167-179, :212-216)
+//   straight   = maximal run of >= 2 consecutive (1,1) nodes; its two end k-mers are the joints (:217-223, :373-391)
+//   coverage   = CountNodeCoverage (:393-449) with its quirks (both strands counted separately; the base after the
+//                first window read even when the read has exactly k bases)
+//   GFA        = PrintGraph (:451-544): S lines, then for every junction the L lines of its read-supported,
+//                Bloom-positive neighbours
+// Node ids and line order are ours; parity is defined on the ID-free canonical form (tests/gfa_canon.py).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "p3_oracle.h"
+
+typedef unsigned __int128 u128;
+
+namespace {
+
+struct H128 {
+  size_t operator()(const u128& v) const {
+    uint64_t a = (uint64_t)v, b = (uint64_t)(v >> 64);
+    a ^= b * 0x9E3779B97F4A7C15ULL;
+    a ^= a >> 29;
+    a *= 0xBF58476D1CE4E5B9ULL;
+    a ^= a >> 32;
+    return (size_t)a;
+  }
+};
+
+struct Ctx {
+  int k, H, nw;
+  uint64_t m;
+  const uint64_t* bloom;
+  u128 mask;
+  u128 rc(u128 x) const {
+    u128 o = 0;
+    for (int i = 0; i < k; i++) {
+      o = (o << 2) | (u128)(3 - (unsigned)((x >> (2 * i)) & 3));
+    }
+    return o;
+  }
+  u128 canon(u128 x) const {
+    u128 r = rc(x);
+    return x <= r ? x : r;
+  }
+  bool recorded(u128 x) const {  // IsRecorded, src/DeBruijnGraph.cpp:317-323
+    u128 c = canon(x);
+    uint64_t w[2] = {(uint64_t)c, (uint64_t)(c >> 64)};
+    uint8_t out;
+    p3o_bloom_query(bloom, m, H, w, 1, k, &out);
+    return out != 0;
+  }
+  u128 left_of(u128 x, unsigned b) const { return (x >> 2) | ((u128)b << (2 * k - 2)); }
+  u128 right_of(u128 x, unsigned b) const { return ((x << 2) | b) & mask; }
+  std::string str(u128 x) const {
+    static const char b2c[4] = {'A', 'C', 'G', 'T'};
+    std::string s((size_t)k, 'A');
+    for (int i = 0; i < k; i++) s[(size_t)i] = b2c[(unsigned)((x >> (2 * (k - 1 - i))) & 3)];
+    return s;
+  }
+};
+
+struct Node {
+  uint8_t nl = 0, nr = 0;
+  u128 l[4], r[4];       // neighbours in the node's canonical orientation
+  int junction_id = 0;   // > 0: junction
+  int straight_id = 0;   // > 0: member of that straight
+  bool joint = false;
+  // junction counters (canonical orientation)
+  int coverage = 0, lcov[4] = {0, 0, 0, 0}, rcov[4] = {0, 0, 0, 0};
+};
+
+typedef std::unordered_map<u128, Node, H128> NodeMap;
+
+inline unsigned fcode(char c) { return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0; }
+inline unsigned ccode(char c) { return c == 'A' ? 3 : c == 'C' ? 2 : c == 'G' ? 1 : 0; }  // comp. code; unknown -> 0
+
+}  // namespace
+
+extern "C" {
+
+void p3o_free(char* p) { delete[] p; }
+
+// Returns the GFA text (reference format) in a new[]-allocated buffer (*out_text, *out_len); 0 on success.
+int p3o_dbg(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+            const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
+            char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights) {
+  if (k < 21 || k > 64) return 2;
+  Ctx cx;
+  cx.k = k;
+  cx.H = H;
+  cx.m = m;
+  cx.bloom = bloom_words;
+  cx.nw = (2 * k + 63) / 64;
+  cx.mask = (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+  NodeMap nodes;
+  // ---- closure of the seeds (G4) ----
+  std::deque<u128> q;
+  for (uint64_t i = 0; i < n_seeds; i++) {
+    u128 s = seed_keys[i * cx.nw];
+    if (cx.nw == 2) s |= (u128)seed_keys[i * cx.nw + 1] << 64;
+    q.push_back(s);
+  }
+  while (!q.empty()) {
+    u128 c = cx.canon(q.front());
+    q.pop_front();
+    if (nodes.count(c)) continue;
+    Node n;
+    for (unsigned b = 0; b < 4; b++) {
+      u128 a = cx.left_of(c, b);
+      if (cx.recorded(a)) n.l[n.nl++] = a;
+    }
+    for (unsigned b = 0; b < 4; b++) {
+      u128 a = cx.right_of(c, b);
+      if (cx.recorded(a)) n.r[n.nr++] = a;
+    }
+    nodes.emplace(c, n);
+    for (int i = 0; i < n.nl; i++) q.push_back(n.l[i]);
+    for (int i = 0; i < n.nr; i++) q.push_back(n.r[i]);
+  }
+  auto is11 = [&](u128 oriented) {
+    const Node& n = nodes.at(cx.canon(oriented));
+    return n.nl == 1 && n.nr == 1;
+  };
+  // oriented right / left neighbour of an oriented (1,1) node
+  auto right1 = [&](u128 x) {
+    u128 c = cx.canon(x);
+    const Node& n = nodes.at(c);
+    return x == c ? n.r[0] : cx.rc(n.l[0]);
+  };
+  auto left1 = [&](u128 x) {
+    u128 c = cx.canon(x);
+    const Node& n = nodes.at(c);
+    return x == c ? n.l[0] : cx.rc(n.r[0]);
+  };
+  // ---- classification: junctions, straights, joints ----
+  int junction_id = 0, straight_id = 0;
+  struct Straight {
+    std::string seq;
+    u128 left_joint, right_joint;  // oriented as in seq
+  };
+  std::vector<Straight> straights;
+  std::unordered_map<u128, int, H128> joint_of;  // oriented joint k-mer (as stored) -> straight id
+  std::vector<u128> order;
+  order.reserve(nodes.size());
+  for (auto& kv : nodes) order.push_back(kv.first);
+  std::sort(order.begin(), order.end());  // deterministic ids
+  for (u128 c : order) {
+    Node& n = nodes[c];
+    if (!(n.nl == 1 && n.nr == 1)) n.junction_id = ++junction_id;
+  }
+  const size_t guard = nodes.size() + 2;
+  for (u128 c : order) {
+    Node& n = nodes[c];
+    if (n.junction_id || n.straight_id) continue;
+    // walk left to the start of the run (orientation: canonical orientation of c)
+    u128 start = c;
+    size_t steps = 0;
+    while (steps++ < guard) {
+      u128 p = left1(start);
+      if (!is11(p) || cx.canon(p) == cx.canon(c)) break;
+      start = p;
+    }
+    // walk right collecting the run
+    std::vector<u128> run;
+    run.push_back(start);
+    steps = 0;
+    while (steps++ < guard) {
+      u128 nx = right1(run.back());
+      if (!is11(nx) || cx.canon(nx) == cx.canon(start)) break;
+      run.push_back(nx);
+    }
+    if (run.size() == 1) {
+      n.junction_id = ++junction_id;  // "this node cannot extend" (:212-216)
+      continue;
+    }
+    Straight st;
+    st.seq = cx.str(run[0]);
+    static const char b2c[4] = {'A', 'C', 'G', 'T'};
+    for (size_t i = 1; i < run.size(); i++) st.seq += b2c[(unsigned)(run[i] & 3)];
+    st.left_joint = run.front();
+    st.right_joint = run.back();
+    straights.push_back(st);
+    ++straight_id;
+    for (u128 x : run) nodes[cx.canon(x)].straight_id = straight_id;
+    nodes[cx.canon(run.front())].joint = true;
+    nodes[cx.canon(run.back())].joint = true;
+    joint_of[run.front()] = straight_id;
+    joint_of[run.back()] = straight_id;
+  }
+  // ---- coverage (G5): junction keys are stored in canonical orientation here ----
+  auto junction_at = [&](u128 key) -> Node* {  // exact-orientation lookup, like junctions.find(key)
+    auto it = nodes.find(key);
+    if (it == nodes.end() || !it->second.junction_id) return nullptr;
+    return &it->second;  // map key == canonical == stored orientation
+  };
+  for (uint64_t r = 0; r < n_reads; r++) {
+    const char* s = bases + offsets[r];
+    const uint64_t L = offsets[r + 1] - offsets[r];
+    if (L < min_len || L < (uint64_t)k) continue;
+    u128 fw = 0, bw = 0;
+    for (uint64_t i = 0; i < L; i++) {
+      fw = ((fw << 2) | fcode(s[i])) & cx.mask;
+      bw = (bw >> 2) | ((u128)ccode(s[i]) << (2 * k - 2));
+      if (i + 1 < (uint64_t)k) continue;
+      Node* jf = junction_at(fw);
+      Node* jb = junction_at(bw);
+      if (jf) jf->coverage++;
+      if (jb) jb->coverage++;
+      const char nxt = (i + 1 < L) ? s[i + 1] : '\0';
+      if (i + 1 == (uint64_t)k) {  // first window (:407-413): reads read[k] unguarded
+        if (jf) jf->rcov[fcode(nxt)]++;
+        else if (jb) jb->lcov[ccode(nxt)]++;
+      } else {
+        const char prv = s[i - k];
+        if (jf) {
+          jf->lcov[fcode(prv)]++;
+          if (i < L - 1) jf->rcov[fcode(nxt)]++;
+        } else if (jb) {
+          jb->rcov[ccode(prv)]++;
+          if (i < L - 1) jb->lcov[ccode(nxt)]++;
+        }
+      }
+    }
+  }
+  // ---- GFA text (G6) ----
+  std::string out = "H\tVN:Z:1.0\n";
+  for (size_t i = 0; i < straights.size(); i++)
+    out += "S\tStraight_" + std::to_string(i + 1) + "\t" + straights[i].seq + "\tKC:i:" + std::to_string(straights[i].seq.size()) + "\n";
+  for (u128 c : order) {
+    const Node& n = nodes[c];
+    if (n.junction_id)
+      out += "S\tJunction_" + std::to_string(n.junction_id) + "\t" + cx.str(c) + "\tKC:i:" + std::to_string((long long)n.coverage * k) + "\n";
+  }
+  const std::string ov = std::to_string(k - 1) + "M\n";
+  auto name_of = [&](u128 x, std::string& nm, char& orient) -> bool {
+    // junctions.find(x) / joints.find(x), then the complement (:474-505)
+    if (Node* j = junction_at(x)) {
+      nm = "Junction_" + std::to_string(j->junction_id);
+      orient = '+';
+      return true;
+    }
+    auto it = joint_of.find(x);
+    if (it != joint_of.end()) {
+      nm = "Straight_" + std::to_string(it->second);
+      orient = '+';
+      return true;
+    }
+    u128 y = cx.rc(x);
+    if (Node* j = junction_at(y)) {
+      nm = "Junction_" + std::to_string(j->junction_id);
+      orient = '-';
+      return true;
+    }
+    it = joint_of.find(y);
+    if (it != joint_of.end()) {
+      nm = "Straight_" + std::to_string(it->second);
+      orient = '-';
+      return true;
+    }
+    return false;
+  };
+  for (u128 c : order) {
+    const Node& n = nodes[c];
+    if (!n.junction_id) continue;
+    const std::string me = "Junction_" + std::to_string(n.junction_id);
+    for (unsigned b = 0; b < 4; b++) {
+      if (n.lcov[b] == 0) continue;
+      u128 a = cx.left_of(c, b);
+      if (!cx.recorded(a)) continue;
+      std::string nm;
+      char o;
+      if (name_of(a, nm, o)) out += "L\t" + nm + "\t" + o + "\t" + me + "\t+\t" + ov;
+    }
+    for (unsigned b = 0; b < 4; b++) {
+      if (n.rcov[b] == 0) continue;
+      u128 a = cx.right_of(c, b);
+      if (!cx.recorded(a)) continue;
+      std::string nm;
+      char o;
+      if (name_of(a, nm, o)) out += "L\t" + me + "\t+\t" + nm + "\t" + o + "\t" + ov;
+    }
+  }
+  char* buf = new char[out.size() + 1];
+  std::memcpy(buf, out.data(), out.size() + 1);
+  *out_text = buf;
+  *out_len = out.size();
+  if (n_junctions) *n_junctions = (uint64_t)junction_id;
+  if (n_joints) *n_joints = joint_of.size();
+  if (n_straights) *n_straights = straights.size();
+  return 0;
+}
+
+}  // extern "C"
