@@ -120,6 +120,27 @@ int p3_get_bloom_stats(p3_ctx* ctx, p3_bloom_stats* out);
 /* keys: n * nw words (canonical or not -- queried as given, like the reference). out[i] in {0,1}. */
 int p3_bloom_query(p3_ctx* ctx, const uint64_t* keys, uint64_t n, uint8_t* out);
 
+/* ---- G3-G6: DeBruijnGraph<B> (src/DeBruijnGraph.cpp:33-544) ------------------------------------------------------- */
+/* p3_build_graph = MakeDBG(seeds) + CountNodeCoverage(reads) on the device, from the resident Bloom vector, seeds
+ * and reads of the preceding p3_make_bloom.  The node set, the junction / straight classification, coverage counters
+ * and links equal the reference's `-t 1` result in the ID-free canonical form (ids and line order differ; the
+ * reference's own ids change with -t).  Inputs must be ACGT-only for the junction coverage to be defined without
+ * reference to discovery order.  Exports mirror the G3 structs:
+ *   junction i : key (nw words), JunctionInfo::coverage, left_kmers_cov[4], right_kmers_cov[4]   (id = i+1)
+ *   straight i : StraightInfo::sequence = seq[seq_off[i] .. seq_off[i+1])                           (id = i+1)
+ *   edge       : one PrintGraph L line "A oA B oB (k-1)M"; A,B: bit 31 = straight, bit 30 = '-', low bits = id-1 */
+typedef struct {
+  uint64_t n_nodes, n_junctions, n_joints, n_straights, straight_bases, n_edges, levels;
+} p3_graph_stats;
+int p3_build_graph(p3_ctx* ctx);
+int p3_get_graph_stats(p3_ctx* ctx, p3_graph_stats* out);
+int p3_export_junctions(p3_ctx* ctx, uint64_t* keys, int32_t* coverage, int32_t* left_cov, int32_t* right_cov,
+                        uint64_t cap, uint64_t* n);
+int p3_export_straights(p3_ctx* ctx, uint64_t* seq_off, char* seq, uint64_t cap_n, uint64_t cap_bases, uint64_t* n);
+int p3_export_edges(p3_ctx* ctx, uint32_t* a, uint32_t* b, uint64_t cap, uint64_t* n);
+/* PrintGraph (src/DeBruijnGraph.cpp:451-544): GFA 1.0 text in the reference's format */
+int p3_write_gfa(p3_ctx* ctx, const char* path);
+
 /* ---- convenience: the whole timed pass (C1 + G1 + G2) with results left resident in HBM ---------- */
 int p3_run_pass(p3_ctx* ctx, uint32_t k, uint64_t m_bits, uint32_t H);
 

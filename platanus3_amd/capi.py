@@ -30,6 +30,11 @@ class BloomStats(C.Structure):
     _fields_ = [("n_windows_k", C.c_uint64), ("n_passing", C.c_uint64), ("n_seed_reads", C.c_uint64)]
 
 
+class GraphStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_nodes", "n_junctions", "n_joints", "n_straights", "straight_bases", "n_edges",
+                                           "levels")]
+
+
 class Timings(C.Structure):
     _fields_ = [("ms_pack", C.c_float), ("ms_count", C.c_float), ("ms_gate", C.c_float), ("ms_bloom", C.c_float),
                 ("ms_seeds", C.c_float), ("ms_total", C.c_float)]
@@ -84,6 +89,12 @@ def load(build=False):
     L.p3_get_bloom_stats.argtypes = [vp, C.POINTER(BloomStats)]
     L.p3_bloom_query.argtypes = [vp, vp, u64, vp]
     L.p3_run_pass.argtypes = [vp, u32, u64, u32]
+    L.p3_build_graph.argtypes = [vp]
+    L.p3_get_graph_stats.argtypes = [vp, C.POINTER(GraphStats)]
+    L.p3_export_junctions.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
+    L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]
+    L.p3_export_edges.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.p3_write_gfa.argtypes = [vp, C.c_char_p]
     L.p3_mr_config.argtypes = [vp, u32, u32]
     L.p3_mr_count_partition.argtypes = [vp]
     L.p3_mr_count_send_layout.argtypes = [vp, C.POINTER(MrSendLayout)]
@@ -217,6 +228,31 @@ class Context:
         out = np.zeros(max(1, n), np.uint8)
         self._chk(self.L.p3_bloom_query(self.h, keys.ctypes.data, n, out.ctypes.data))
         return out[:n]
+
+    # ---- G3-G6 ---------------------------------------------------------------------------------------
+    def build_graph(self):
+        self._chk(self.L.p3_build_graph(self.h))
+        return self.graph_stats()
+
+    def graph_stats(self):
+        g = GraphStats()
+        self._chk(self.L.p3_get_graph_stats(self.h, C.byref(g)))
+        return {f: getattr(g, f) for f, _ in GraphStats._fields_}
+
+    def write_gfa(self, path):
+        self._chk(self.L.p3_write_gfa(self.h, path.encode()))
+
+    def export_junctions(self):
+        g = self.graph_stats()
+        nj, nw = g["n_junctions"], nwords(self.k)
+        keys = np.zeros(max(1, nj) * nw, np.uint64)
+        cov = np.zeros(max(1, nj), np.int32)
+        lc = np.zeros(max(1, nj) * 4, np.int32)
+        rc = np.zeros(max(1, nj) * 4, np.int32)
+        n = C.c_uint64()
+        self._chk(self.L.p3_export_junctions(self.h, keys.ctypes.data, cov.ctypes.data, lc.ctypes.data, rc.ctypes.data,
+                                             max(1, nj), C.byref(n)))
+        return keys[:nj * nw].reshape(nj, nw), cov[:nj], lc[:nj * 4].reshape(nj, 4), rc[:nj * 4].reshape(nj, 4)
 
     # ---- multi-rank protocol (device pointers are returned as plain ints) ----------------------------
     def mr_config(self, rank, n_ranks):

@@ -1,0 +1,54 @@
+"""GPU tier: the de Bruijn stage (p3_build_graph / p3_write_gfa) against the golden
+canonical GFA forms the REAL reference produced with -t 1, and against the oracle on other inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import platanus3_amd.synth as synth
+from platanus3_amd import capi
+from gfa_canon import canonical
+from test_oracle_dbg import check_against_golden, dbg_cases, load_dbg_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_gfa(ctx, b, off, k, m, H, tmp_path):
+    ctx.load_reads(b, off, min_len=k)
+    ctx.run_pass(k, m, H)
+    st = ctx.build_graph()
+    path = os.path.join(str(tmp_path), "g.gfa")
+    ctx.write_gfa(path)
+    return open(path).read(), st
+
+
+@pytest.mark.parametrize("case", dbg_cases(), ids=lambda c: c["name"])
+def test_graph_matches_reference_gfa(ctx, tmp_path, case):
+    b, off = load_dbg_reads(case["name"])
+    gfa, st = gpu_gfa(ctx, b, off, case["k"], case["m"], case["H"], tmp_path)
+    assert st["n_junctions"] == case["n_junctions"] and st["n_straights"] == case["n_straights"]
+    check_against_golden(case, gfa)
+
+
+@pytest.mark.parametrize("k,n,m,H", [(31, 20000, None, None), (27, 5000, 1 << 22, 10), (45, 5000, 1 << 23, 10),
+                                     (63, 4000, 1 << 23, 10)])
+def test_graph_vs_oracle(ctx, oracle, tmp_path, k, n, m, H):
+    b, off = synth.reads(seed=50 + k, total_reads=n, read_len=150)
+    if m is None:
+        m, H = oracle.estimate_bloom(int(b.size), k)
+    gfa, st = gpu_gfa(ctx, b, off, k, m, H, tmp_path)
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    want, ost = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
+    assert st["n_junctions"] == ost["junctions"] and st["n_straights"] == ost["straights"]
+    gn, ge = canonical(gfa)
+    wn, we = canonical(want)
+    assert gn == wn
+    assert ge == we
