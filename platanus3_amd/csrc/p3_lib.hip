@@ -842,7 +842,12 @@ int build_graph_t(p3_ctx* c) {
   u64 hc[16];
   u64 levels = 0;
   for (int attempt = 0;; attempt++) {
-    if (attempt > 6) return fail(c, P3_ECAPACITY, "de Bruijn node table keeps overflowing");
+    // The closure is bounded only by the filter's false-positive rate: with a dense filter (the reference's default
+    // sizing reaches ~90 % set bits on small inputs) false neighbours breed faster than they die out and the node set
+    // grows without limit (the reference itself does not terminate there).  Refuse beyond 64x the estimate.
+    if (attempt > 3)
+      return fail(c, P3_ECAPACITY, "de Bruijn closure exceeds %llu nodes: Bloom filter too dense for a finite graph",
+                  (unsigned long long)(cap / 8));
     c->g_cap = cap;
     const u64 node_limit = cap / 2 + cap / 8;  // 62 % load at most
     const u64 fcap = 8 * node_limit + 64;       // every inserted node appends at most 8 neighbours

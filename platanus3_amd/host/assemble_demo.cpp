@@ -1,6 +1,6 @@
 // assemble_demo.cpp -- the reference's Assemble<B> call order (src/Assemble.cpp:9-12) through the shim.
 //
-//   assemble_demo <reads.fasta> <k> <m> <H> <out_prefix>
+//   assemble_demo <reads.fasta> <k> <m> <H> <out_prefix> [graph]
 //
 // Writes <out_prefix>.counts (key<TAB>count, sorted), <out_prefix>.bloom (uint64 words) and
 // <out_prefix>.seeds (one per line, std::set order).  FASTA reading here is a 10-line stand-in for
@@ -10,6 +10,8 @@
 #include <iostream>
 
 #include "platanus3_shim.hpp"
+
+static bool g_with_graph = false;
 
 template <typename B>
 int run(ReadFile& input_reads, int k, uint64_t m, int H, const std::string& out) {
@@ -30,15 +32,25 @@ int run(ReadFile& input_reads, int k, uint64_t m, int H, const std::string& out)
   fb.write((const char*)words.data(), words.size() * 8);
   std::ofstream fs(out + ".seeds");
   for (const auto& s : seedkmer) fs << s << "\n";
-  // B2 on the host object: every seed's canonical form must be reported present
+  if (!g_with_graph) return 0;
+  // the rest of Assemble<B> (src/Assemble.cpp:19-26): graph, coverage, GFA (written to ./de_bruijn_graph.gfa)
+  DeBruijnGraph<B> first_dbg(k, bf, logging);
+  first_dbg.MakeDBG(seedkmer, m, (uint8_t)H, 8);
+  first_dbg.CountNodeCoverage(input_reads.reads);
+  first_dbg.PrintGraph();
+  std::ofstream fg(out + ".graph");
+  long long covsum = 0;
+  for (const auto& kv : first_dbg.junctions) covsum += kv.second.coverage;
+  fg << first_dbg.junctions.size() << " " << first_dbg.joints.size() << " " << first_dbg.straights.size() << " " << covsum << "\n";
   return 0;
 }
 
 int main(int argc, char** argv) {
-  if (argc != 6) {
-    std::cerr << "usage: assemble_demo reads.fasta k m H out_prefix\n";
+  if (argc != 6 && argc != 7) {
+    std::cerr << "usage: assemble_demo reads.fasta k m H out_prefix [graph]\n";
     return 2;
   }
+  g_with_graph = argc == 7;
   const int k = std::stoi(argv[2]);
   const uint64_t m = std::stoull(argv[3]);
   const int H = std::stoi(argv[4]);

@@ -239,4 +239,128 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
   return bf;
 }
 
+// ---- DeBruijnGraph<LARGE_BITSET>: src/DeBruijnGraph.cpp:10-78 (structs and maps), :93 MakeDBG, :393 CountNodeCoverage,
+// :451 PrintGraph.  The traversal, classification, coverage and link emission run on the device (p3_build_graph); the
+// three maps are materialised from its flat exports.  Ids are assigned by the device (the reference's own ids depend on
+// its thread count); keys are stored in canonical orientation (the reference stores "as discovered" and always looks
+// up both orientations, :302-309).  JointInfo::coverage is never printed by the reference and is left 0.
+struct StraightInfo;
+struct JunctionInfo {
+  int id;
+  int coverage = 0;
+  int left_kmers_cov[4] = {0, 0, 0, 0};
+  int right_kmers_cov[4] = {0, 0, 0, 0};
+};
+struct JointInfo {
+  int id;
+  int coverage = 0;
+  StraightInfo* connected_straight = nullptr;
+};
+struct StraightInfo {
+  int id;
+  std::string sequence;
+  JointInfo* left_joint = nullptr;
+  JointInfo* right_joint = nullptr;
+};
+
+template <typename LARGE_BITSET>
+class DeBruijnGraph {
+ public:
+  int kmer_length;
+  int bitset_length;
+  BF<LARGE_BITSET>* all_kmers;
+  Logging* logging;
+  std::unordered_map<LARGE_BITSET, JunctionInfo> junctions;
+  std::unordered_map<LARGE_BITSET, JointInfo> joints;
+  std::unordered_map<int, StraightInfo> straights;
+  int straight_nodes_id = 0, junction_nodes_id = 0, joint_nodes_id = 0;
+
+  DeBruijnGraph(int k, BF<LARGE_BITSET>& first_bloom_filter, Logging& input_logging)
+      : kmer_length(k), bitset_length(2 * k), all_kmers(&first_bloom_filter), logging(&input_logging) {}
+
+  // MakeDBG (:93-155).  The seed set, filter size and hash count live in the device context of the MakeBF call that
+  // produced `first_bloom_filter`; the arguments are accepted for signature compatibility (the reference ignores the
+  // last three itself).
+  void MakeDBG(std::set<std::string>& seedkmer, uint64_t, uint8_t, int) {
+    (void)seedkmer;
+    p3_ctx* ctx = p3shim::Session::get().context();
+    p3shim::check(ctx, p3_build_graph(ctx), "p3_build_graph");
+    p3_graph_stats g;
+    p3shim::check(ctx, p3_get_graph_stats(ctx, &g), "p3_get_graph_stats");
+    const int nw = (bitset_length + 63) / 64;
+    std::vector<uint64_t> keys((g.n_junctions + 1) * nw), so(g.n_straights + 1);
+    cov_.assign(g.n_junctions + 1, 0);
+    lcov_.assign((g.n_junctions + 1) * 4, 0);
+    rcov_.assign((g.n_junctions + 1) * 4, 0);
+    std::vector<char> seq(g.straight_bases + 1);
+    uint64_t n = 0;
+    p3shim::check(ctx, p3_export_junctions(ctx, keys.data(), cov_.data(), lcov_.data(), rcov_.data(), g.n_junctions + 1, &n),
+                  "p3_export_junctions");
+    p3shim::check(ctx, p3_export_straights(ctx, so.data(), seq.data(), g.n_straights + 1, g.straight_bases + 1, &n),
+                  "p3_export_straights");
+    junction_keys_.clear();
+    for (uint64_t i = 0; i < g.n_junctions; i++) {
+      LARGE_BITSET key = to_bitset(&keys[i * nw], nw);
+      junctions[key].id = (int)(i + 1);
+      junction_keys_.push_back(key);
+    }
+    junction_nodes_id = (int)g.n_junctions;
+    for (uint64_t i = 0; i < g.n_straights; i++) {
+      StraightInfo& st = straights[(int)(i + 1)];
+      st.id = (int)(i + 1);
+      st.sequence.assign(seq.data() + so[i], seq.data() + so[i + 1]);
+      LARGE_BITSET lj = encode(st.sequence.substr(0, (size_t)kmer_length));
+      LARGE_BITSET rj = encode(st.sequence.substr(st.sequence.size() - (size_t)kmer_length));
+      joints[lj].id = ++joint_nodes_id;
+      joints[rj].id = ++joint_nodes_id;
+    }
+    for (auto& kv : straights) {  // pointers after the maps stopped growing
+      StraightInfo& st = kv.second;
+      st.left_joint = &joints[encode(st.sequence.substr(0, (size_t)kmer_length))];
+      st.right_joint = &joints[encode(st.sequence.substr(st.sequence.size() - (size_t)kmer_length))];
+      st.left_joint->connected_straight = &st;
+      st.right_joint->connected_straight = &st;
+    }
+    straight_nodes_id = (int)g.n_straights;
+  }
+
+  // CountNodeCoverage (:393-439): the counters were accumulated on the device by p3_build_graph
+  void CountNodeCoverage(ReadSet&) {
+    for (size_t i = 0; i < junction_keys_.size(); i++) {
+      JunctionInfo& j = junctions[junction_keys_[i]];
+      j.coverage = cov_[i];
+      for (int b = 0; b < 4; b++) {
+        j.left_kmers_cov[b] = lcov_[i * 4 + b];
+        j.right_kmers_cov[b] = rcov_[i * 4 + b];
+      }
+    }
+  }
+
+  // PrintGraph (:451-544): ./de_bruijn_graph.gfa, same format; ids are the device's
+  void PrintGraph() {
+    p3_ctx* ctx = p3shim::Session::get().context();
+    p3shim::check(ctx, p3_write_gfa(ctx, "./de_bruijn_graph.gfa"), "p3_write_gfa");
+  }
+
+ private:
+  std::vector<LARGE_BITSET> junction_keys_;
+  std::vector<int32_t> cov_, lcov_, rcov_;
+  static LARGE_BITSET to_bitset(const uint64_t* w, int nw) {
+    LARGE_BITSET b(w[0]);
+    if (nw == 2) {
+      LARGE_BITSET hi(w[1]);
+      b |= (hi << 64);
+    }
+    return b;
+  }
+  LARGE_BITSET encode(const std::string& s) const {  // GetFirstKmerForward (src/BitCalc.cpp:7-19) on an ACGT string
+    LARGE_BITSET b(0);
+    for (char ch : s) {
+      b <<= 2;
+      b |= LARGE_BITSET(ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 0);
+    }
+    return b;
+  }
+};
+
 #endif  // PLATANUS3_SHIM_HPP

@@ -52,3 +52,14 @@ def test_graph_vs_oracle(ctx, oracle, tmp_path, k, n, m, H):
     wn, we = canonical(want)
     assert gn == wn
     assert ge == we
+
+
+def test_dense_filter_is_refused_not_hung(ctx):
+    """With a nearly full Bloom vector false-positive neighbours breed without limit (the reference does not
+    terminate on such inputs); the device stage must stop with P3_ECAPACITY instead of growing forever."""
+    b, off = synth.reads(seed=77, total_reads=300, read_len=150)
+    ctx.load_reads(b, off, min_len=31)
+    ctx.run_pass(31, 3000, 19)  # ~all bits set
+    with pytest.raises(capi.P3Error) as e:
+        ctx.build_graph()
+    assert e.value.code == 3

@@ -40,9 +40,32 @@ def test_shim_matches_reference_golden(tmp_path, name):
         for i, r in enumerate(c["reads"]):
             f.write(">r%d\n%s\n" % (i, r.decode()))
     out = os.path.join(str(tmp_path), "out")
-    subprocess.check_call([exe, fa, str(c["k"]), str(c["m"]), str(c["H"]), out])
+    subprocess.check_call([exe, fa, str(c["k"]), str(c["m"]), str(c["H"]), out], cwd=str(tmp_path), timeout=120)
     kc = np.loadtxt(out + ".counts", dtype=np.uint64, ndmin=2)
     assert np.array_equal(kc[:, 0], c["keys"]) and np.array_equal(kc[:, 1], c["counts"])
     assert np.array_equal(np.fromfile(out + ".bloom", dtype=np.uint64), c["bloom"])
     seeds = [s for s in open(out + ".seeds").read().split("\n") if s]
     assert seeds == c["seeds"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synth2000_k31", "synth1000_k41", "long40_k63"])
+def test_shim_full_assemble_gfa(tmp_path, name):
+    """The whole Assemble<B> sequence through the shim (CountShortKmer, MakeBF, DeBruijnGraph::MakeDBG,
+    CountNodeCoverage, PrintGraph): the GFA equals the reference's in canonical form."""
+    import json
+    from test_oracle_dbg import check_against_golden, load_dbg_reads
+    from util import GOLDEN
+    case = [c for c in json.load(open(os.path.join(GOLDEN, "dbg_cases.json"))) if c["name"] == name][0]
+    exe = _compile(tmp_path)
+    b, off = load_dbg_reads(name)
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(off.size - 1):
+            f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
+    out = os.path.join(str(tmp_path), "out")
+    subprocess.check_call([exe, fa, str(case["k"]), str(case["m"]), str(case["H"]), out, "graph"], cwd=str(tmp_path),
+                          timeout=120)
+    check_against_golden(case, open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
+    nj, njo, ns, covsum = [int(x) for x in open(out + ".graph").read().split()]
+    assert nj == case["n_junctions"] and ns == case["n_straights"] and njo <= 2 * ns
