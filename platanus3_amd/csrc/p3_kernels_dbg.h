@@ -1,8 +1,8 @@
 // p3_kernels_dbg.h -- the de Bruijn stage on the device (gfx950, wave64).
 //
 // The reference grows the graph by a seeded, lock-protected traversal (src/DeBruijnGraph.cpp:93-391).  What that
-// traversal produces is order-independent (validated against the reference's GFA in canonical form, see
-// oracle/p3_oracle_dbg.cpp), which is what makes a level-synchronous device formulation possible:
+// traversal produces is order-independent (validated against the reference's GFA in canonical form by the test
+// suite's CPU checker), which is what makes a level-synchronous device formulation possible:
 //
 //   k_dbg_expand    frontier k-mers -> node table insert (canonical key) + the 8 Bloom-queried neighbours
 //                   (CheckDirections/IsRecorded, :317-345); new neighbours form the next frontier
