@@ -52,46 +52,216 @@ struct EstSeg {
   u64* ovf;
 };
 
-// ---- generic LDS stager: rows of 128 bytes (2 chunks), flushed by 4 lanes per bucket ----------------------
+__device__ __forceinline__ u32 seg_base(const u32* __restrict__ seg_off, u32 bucket, const EstSeg& est) {
+  return est.segcap ? (bucket * P3_NWG + blockIdx.x) * est.segcap : seg_off[bucket * P3_NWG + blockIdx.x];
+}
+
+// ---- generic LDS stager ---------------------------------------------------------------------------------------
+// One 128-byte row per bucket, used as a ring of two 64-byte chunks.  cnt[b] = (parity << 31) | tickets: `parity`
+// is the chunk the ring currently starts at, `tickets` the records staged since the last flush (tickets >= CAP
+// were refused and are voided by the flush).  wpos[b] = records already written to the (bucket, workgroup)
+// segment, segb[b] its base.  Flush: thread t inspects row t, the rows with a full chunk are listed per wave
+// (ballot + mbcnt) and drained 16 at a time by groups of 4 lanes (16 B each) -- nothing is moved inside LDS.
+// Needs blockDim.x == P3_NB.  LDS words: P3_STAGE_WORDS.
+#define P3_STAGE_WORDS (P3_NB * 32 + 3 * P3_NB + P3_NB / 2 + 4)
+static_assert(P3_PART_THREADS == P3_NB, "stager: one thread per row");
+
+struct StageLds {
+  uint4* rows;
+  u32* cnt;
+  u32* wpos;
+  u32* segb;
+  unsigned short* list;
+  u32* flag;  // two words: "some lane still holds a refused record", alternating per round
+};
+
+__device__ __forceinline__ StageLds stage_layout(u32* lds) {
+  StageLds s;
+  s.rows = reinterpret_cast<uint4*>(lds);
+  s.cnt = lds + P3_NB * 32;
+  s.wpos = s.cnt + P3_NB;
+  s.segb = s.wpos + P3_NB;
+  s.list = reinterpret_cast<unsigned short*>(s.segb + P3_NB);
+  s.flag = s.segb + P3_NB + P3_NB / 2;
+  return s;
+}
+
 template <typename REC>
-__device__ __forceinline__ void stage_flush(uint4* stage16, u32* cnt, u32* wpos, const u32* segb, REC* __restrict__ out,
-                                            bool final_flush, const EstSeg est = EstSeg{0, nullptr, nullptr}) {
+__device__ __forceinline__ bool stage_put(const StageLds& s, u32 b, const REC& rec) {
   constexpr u32 CHUNK = Stg<REC>::CHUNK, CAP = Stg<REC>::CAP;
-  const u32 q = threadIdx.x & 3;
-  for (u32 it = 0; it < P3_NB / (P3_PART_THREADS / 4); it++) {
-    const u32 b = it * (P3_PART_THREADS / 4) + (threadIdx.x >> 2);
-    u32 n = cnt[b];
-    n = n < CAP ? n : CAP;
-    u32 nfl = (n / CHUNK) * CHUNK;
-    if (final_flush && (n % CHUNK)) nfl += CHUNK;
-    if (nfl) {
-      if (est.segcap && wpos[b] + nfl > est.segcap) {
+  const u32 v = atomicAdd(&s.cnt[b], 1u);
+  const u32 pos = v & 0x7fffffffu;
+  if (pos >= CAP) return false;
+  reinterpret_cast<REC*>(s.rows + b * 8)[(pos + (v >> 31) * CHUNK) & (CAP - 1)] = rec;
+  return true;
+}
+
+template <typename REC>
+__device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__ out, bool final_flush, const EstSeg est) {
+  constexpr u32 CHUNK = Stg<REC>::CHUNK, CAP = Stg<REC>::CAP;
+  const u32 t = threadIdx.x;
+  u32 n0 = s.cnt[t] & 0x7fffffffu;
+  n0 = n0 < CAP ? n0 : CAP;
+  const bool ready = final_flush ? (n0 != 0) : (n0 >= CHUNK);
+  const u64 mask = __ballot(ready);
+  const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+  unsigned short* wl = s.list + (t & ~63u);
+  if (ready) wl[rank] = (unsigned short)t;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const u32 nready = (u32)__popcll(mask);
+  const u32 q = t & 3, g = (t & 63) >> 2;
+  for (u32 i0 = 0; i0 < nready; i0 += 16) {
+    const u32 idx = i0 + g;
+    if (idx < nready) {
+      const u32 b = wl[idx];
+      const u32 v = s.cnt[b];
+      u32 n = v & 0x7fffffffu;
+      n = n < CAP ? n : CAP;
+      const u32 par = v >> 31;
+      u32 nch = n / CHUNK;
+      if (final_flush && (n % CHUNK)) nch++;
+      const u32 wp = s.wpos[b];
+      if (est.segcap && wp + nch * CHUNK > est.segcap) {
         if (q == 0) *est.ovf = 1;  // segment full: results are void, the host re-runs with exact offsets
       } else {
-        uint4* dst = reinterpret_cast<uint4*>(out + segb[b] + wpos[b]);
-        dst[q] = stage16[b * 8 + q];
-        if (nfl == 2 * CHUNK) dst[4 + q] = stage16[b * 8 + 4 + q];
+        uint4* dst = reinterpret_cast<uint4*>(out + s.segb[b] + wp);
+        const uint4* row = s.rows + b * 8;
+        dst[q] = row[par * 4 + q];
+        if (nch == 2) dst[4 + q] = row[(par ^ 1u) * 4 + q];
       }
-    }
-    if (final_flush && est.segcap && q == 0) est.ghist_out[b * P3_NWG + blockIdx.x] = wpos[b] + n;
-    if (!final_flush) {
-      const u32 r = n - nfl;  // < CHUNK records stay and move to the row start (source is in a later chunk)
-      if (nfl) {
-        REC* row = reinterpret_cast<REC*>(stage16 + b * 8);
-        REC tmp[(CHUNK + 3) / 4];
-#pragma unroll
-        for (u32 t = 0; t < (CHUNK + 3) / 4; t++)
-          if (q + 4 * t < r) tmp[t] = row[nfl + q + 4 * t];
-#pragma unroll
-        for (u32 t = 0; t < (CHUNK + 3) / 4; t++)
-          if (q + 4 * t < r) row[q + 4 * t] = tmp[t];
-      }
-      if (q == 0) {
-        cnt[b] = r;
-        wpos[b] += nfl;
+      if (!final_flush && q == 0) {
+        s.cnt[b] = ((par ^ (nch & 1u)) << 31) | (n - nch * CHUNK);
+        s.wpos[b] = wp + nch * CHUNK;
       }
     }
   }
+  if (final_flush && est.segcap) est.ghist_out[t * P3_NWG + blockIdx.x] = s.wpos[t] + n0;
+}
+
+// One insertion round: N fresh records per lane (bit i of `pend` = record i exists) plus the record carried over
+// from the previous round.  A record that finds its row full is carried into the next round (one per lane)
+// rather than costing the workgroup an extra flush; only a lane with two refusals forces the retry loop.
+template <typename REC>
+struct StageCarry {
+  REC rec;
+  u32 bkt;
+  bool has;
+  u32 par;
+};
+
+template <typename REC, int N>
+__device__ __forceinline__ void stage_round(const StageLds& s, REC* __restrict__ out, const EstSeg est, REC (&rec)[N],
+                                            u32 (&bkt)[N], u32 pend, StageCarry<REC>& c) {
+  if (c.has && stage_put<REC>(s, c.bkt, c.rec)) c.has = false;
+  int more;
+  do {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if ((pend & (1u << i)) && stage_put<REC>(s, bkt[i], rec[i])) pend &= ~(1u << i);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (!c.has && (pend & (1u << i))) {
+        c.rec = rec[i];
+        c.bkt = bkt[i];
+        c.has = true;
+        pend &= ~(1u << i);
+      }
+    }
+    // workgroup-wide OR of "pend != 0" with the round's two barriers only: the flag word is written before the
+    // first, read between the two and cleared (by thread 0) after the second; the next round uses the other word
+    if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+    __syncthreads();
+    stage_flush<REC>(s, out, false, est);
+    more = (int)s.flag[c.par];
+    __syncthreads();
+    if (more && threadIdx.x == 0) s.flag[c.par] = 0;
+    c.par ^= 1u;
+  } while (more);
+}
+
+// after the last round: place the carried records, then write the partial chunks
+template <typename REC>
+__device__ __forceinline__ void stage_finish(const StageLds& s, REC* __restrict__ out, const EstSeg est, StageCarry<REC>& c) {
+  for (;;) {
+    if (c.has && stage_put<REC>(s, c.bkt, c.rec)) c.has = false;
+    if (!__syncthreads_or(c.has)) break;
+    stage_flush<REC>(s, out, false, est);
+    __syncthreads();
+  }
+  stage_flush<REC>(s, out, true, est);
+}
+
+// Software-pipelined driver: gen(rec, bkt, pend) produces the next round's records (false = no more rounds; the
+// answer must be uniform over the workgroup).  The records of round r+1 are computed between the two barriers of
+// round r, so that their arithmetic overlaps the LDS/global traffic of the flush in the other waves.
+template <typename REC, int N, typename GEN>
+__device__ __forceinline__ void stage_run(const StageLds& s, REC* __restrict__ out, const EstSeg est, GEN gen) {
+  StageCarry<REC> c;
+  c.has = false;
+  c.bkt = 0;
+  c.par = 0;
+  REC rec[N];
+  u32 bkt[N];
+  u32 pend = 0;
+  bool have = gen(rec, bkt, pend);
+  while (have) {
+    if (c.has && stage_put<REC>(s, c.bkt, c.rec)) c.has = false;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+      if ((pend & (1u << i)) && stage_put<REC>(s, bkt[i], rec[i])) pend &= ~(1u << i);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      if (!c.has && (pend & (1u << i))) {
+        c.rec = rec[i];
+        c.bkt = bkt[i];
+        c.has = true;
+        pend &= ~(1u << i);
+      }
+    }
+    if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+    __syncthreads();
+    REC rec2[N];
+    u32 bkt2[N];
+    u32 pend2 = 0;
+    const bool have2 = gen(rec2, bkt2, pend2);
+    stage_flush<REC>(s, out, false, est);
+    int more = (int)s.flag[c.par];
+    __syncthreads();
+    if (more && threadIdx.x == 0) s.flag[c.par] = 0;
+    c.par ^= 1u;
+    while (more) {  // rare: some lane had two or more refusals
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        if ((pend & (1u << i)) && stage_put<REC>(s, bkt[i], rec[i])) pend &= ~(1u << i);
+      if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+      __syncthreads();
+      stage_flush<REC>(s, out, false, est);
+      more = (int)s.flag[c.par];
+      __syncthreads();
+      if (more && threadIdx.x == 0) s.flag[c.par] = 0;
+      c.par ^= 1u;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      rec[i] = rec2[i];
+      bkt[i] = bkt2[i];
+    }
+    pend = pend2;
+    have = have2;
+  }
+  stage_finish<REC>(s, out, est, c);
+}
+
+__device__ __forceinline__ void stage_init(const StageLds& s, const u32* seg_off, const EstSeg est) {
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+    s.cnt[i] = 0;
+    s.wpos[i] = 0;
+    s.segb[i] = seg_base(seg_off, i, est);
+  }
+  if (threadIdx.x < 2) s.flag[threadIdx.x] = 0;
+  __syncthreads();
 }
 
 // pass bits of the 32 window starts of word w (also returns how many k-windows are valid)
@@ -160,9 +330,6 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
 }
 
 // ---- k_kmer_scatter -----------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 seg_base(const u32* __restrict__ seg_off, u32 bucket, const EstSeg& est) {
-  return est.segcap ? (bucket * P3_NWG + blockIdx.x) * est.segcap : seg_off[bucket * P3_NWG + blockIdx.x];
-}
 
 // FROM_S = false: the pass bitmap P was produced by k_kmer_hist (exact mode).  FROM_S = true (estimated mode, no
 // histogram pass): the windowed AND of S is evaluated here, P is written and the two statistics are accumulated.
@@ -174,19 +341,15 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
                                                                   typename KRec<NW>::type* __restrict__ part,
                                                                   EstSeg est, u64* __restrict__ stats) {
   typedef typename KRec<NW>::type REC;
-  constexpr u32 CAP = Stg<REC>::CAP;
   constexpr int RW = (NW == 1) ? 4 : 2;  // windows per lane per round: inflow/bucket stays well below CAP
   extern __shared__ __align__(16) u32 lds[];
-  uint4* stage16 = reinterpret_cast<uint4*>(lds);  // NB rows x 128 B
-  u32* cnt = lds + P3_NB * 32;
-  u32* wpos = cnt + P3_NB;
-  u32* segb = wpos + P3_NB;
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
-    cnt[i] = 0;
-    wpos[i] = 0;
-    segb[i] = seg_base(seg_off, i, est);
-  }
-  __syncthreads();
+  const StageLds stg = stage_layout(lds);
+  u32* cnt = stg.cnt;
+  stage_init(stg, seg_off, est);
+  StageCarry<REC> carry;
+  carry.has = false;
+  carry.par = 0;
+  carry.bkt = 0;
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
   u32 n_valid = 0, n_pass = 0;
@@ -239,25 +402,10 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
         pbits >>= 1;
         if (active) kr.roll();
       }
-      int more;
-      do {
-#pragma unroll
-        for (int i = 0; i < RW; i++) {
-          if (pend & (1u << i)) {
-            const u32 pos = atomicAdd(&cnt[bkt[i]], 1u);
-            if (pos < CAP) {
-              reinterpret_cast<REC*>(stage16 + bkt[i] * 8)[pos] = rec[i];
-              pend &= ~(1u << i);
-            }
-          }
-        }
-        __syncthreads();
-        stage_flush<REC>(stage16, cnt, wpos, segb, part, false, est);
-        more = __syncthreads_or(pend != 0);
-      } while (more);
+      stage_round<REC, RW>(stg, part, est, rec, bkt, pend, carry);
     }
   }
-  stage_flush<REC>(stage16, cnt, wpos, segb, part, true, est);
+  stage_finish<REC>(stg, part, est, carry);
   if constexpr (FROM_S) {
     __syncthreads();
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;  // the stage is drained: reuse two words for the block totals
@@ -550,20 +698,15 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
     return;
   }
   const u64 n = *n_ptr;
-  constexpr u32 CAP = Stg<u32>::CAP;
-  constexpr u32 PR = 8;  // probes per lane per round
+  constexpr int PR = 8;  // probes per lane per round
   extern __shared__ __align__(16) u32 lds[];
-  uint4* stage16 = reinterpret_cast<uint4*>(lds);
-  u32* stage = lds;
-  u32* cnt = lds + P3_NB * 32;
-  u32* wpos = cnt + P3_NB;
-  u32* segb = wpos + P3_NB;
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
-    cnt[i] = 0;
-    wpos[i] = 0;
-    segb[i] = seg_base(seg_off, i, est);
-  }
-  __syncthreads();
+  const StageLds stg = stage_layout(lds);
+  stage_init(stg, seg_off, est);
+  StageCarry<u32> carry;
+  carry.has = false;
+  carry.par = 0;
+  carry.bkt = 0;
+  carry.rec = 0;
   u64 begin, end;
   pos_key_range(n, blockIdx.x, begin, end);
   const u32 smask = (1u << slice_log2) - 1;
@@ -581,35 +724,20 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
       u32 rec[PR], bkt[PR];
       u32 pend = 0;
 #pragma unroll
-      for (u32 t = 0; t < PR; t++) {
+      for (int t = 0; t < PR; t++) {
         rec[t] = 0;
         bkt[t] = 0;
-        if (active && done + t < H) {
+        if (active && done + (u32)t < H) {
           rec[t] = (u32)pr.r & smask;
           bkt[t] = (u32)(pr.r >> slice_log2);
           pend |= 1u << t;
           probe_step(pr, mm);
         }
       }
-      int more;
-      do {
-#pragma unroll
-        for (u32 t = 0; t < PR; t++) {
-          if (pend & (1u << t)) {
-            const u32 pos = atomicAdd(&cnt[bkt[t]], 1u);
-            if (pos < CAP) {
-              stage[bkt[t] * CAP + pos] = rec[t];
-              pend &= ~(1u << t);
-            }
-          }
-        }
-        __syncthreads();
-        stage_flush<u32>(stage16, cnt, wpos, segb, out, false, est);
-        more = __syncthreads_or(pend != 0);
-      } while (more);
+      stage_round<u32, PR>(stg, out, est, rec, bkt, pend, carry);
     }
   }
-  stage_flush<u32>(stage16, cnt, wpos, segb, out, true, est);
+  stage_finish<u32>(stg, out, est, carry);
 }
 
 // one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else

@@ -26,74 +26,57 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
                                                                       const u32* __restrict__ endm, u64 n_words,
                                                                       const u32* __restrict__ seg_off,
                                                                       u64* __restrict__ part, EstSeg est) {
-  constexpr u32 CAP = Stg<u64>::CAP;
   constexpr int RW = 4;
   extern __shared__ __align__(16) u32 lds[];
-  uint4* stage16 = reinterpret_cast<uint4*>(lds);
-  u32* cnt = lds + P3_NB * 32;
-  u32* wpos = cnt + P3_NB;
-  u32* segb = wpos + P3_NB;
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
-    cnt[i] = 0;
-    wpos[i] = 0;
-    segb[i] = seg_base(seg_off, i, est);
-  }
-  __syncthreads();
+  const StageLds stg = stage_layout(lds);
+  stage_init(stg, seg_off, est);
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
   const u64 vmask = (1ULL << 20) - 1;
-  for (u64 base = begin; base < end; base += blockDim.x) {
-    const u64 w = base + threadIdx.x;
-    const bool active = w < end;
-    LaneWords L;
-    KmerRoll<1> kr;
-    if (active) {
-      L = load_lane_words(fw, rcw, endm, w);
-      kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
-    } else {
-      L.Elo = ~0ULL;
-      L.Ehi = ~0ULL;
-    }
-    for (int round = 0; round < 32 / RW; round++) {
-      u64 rec[RW];
-      u32 bkt[RW];
-      u32 pend = 0;
-#pragma unroll
-      for (int i = 0; i < RW; i++) {
-        rec[i] = 0;
-        bkt[i] = 0;
-        if (active && (L.Elo & vmask) == 0) {
-          u64 lo, hi;
-          kr.canonical(lo, hi);
-          const u64 g = mix42(lo);
-          rec[i] = (((w << 5) + (u64)(round * RW + i)) << 32) | (g & 0xffffffffULL);
-          bkt[i] = (u32)(g >> 32);
-          pend |= 1u << i;
-        }
-        if (active) {
-          kr.roll();
-          shr128(L.Elo, L.Ehi);
-        }
+  u64 base = begin;
+  int round = 32 / RW;  // "tile exhausted": the first call loads the first tile
+  bool first = true;
+  u64 w = 0;
+  bool active = false;
+  LaneWords L;
+  KmerRoll<1> kr;
+  stage_run<u64, RW>(stg, part, est, [&](u64 (&rec)[RW], u32 (&bkt)[RW], u32& pend) -> bool {
+    if (round == 32 / RW) {
+      if (!first) base += blockDim.x;
+      first = false;
+      if (base >= end) return false;
+      round = 0;
+      w = base + threadIdx.x;
+      active = w < end;
+      if (active) {
+        L = load_lane_words(fw, rcw, endm, w);
+        kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+      } else {
+        L.Elo = ~0ULL;
+        L.Ehi = ~0ULL;
       }
-      int more;
-      do {
-#pragma unroll
-        for (int i = 0; i < RW; i++) {
-          if (pend & (1u << i)) {
-            const u32 pos = atomicAdd(&cnt[bkt[i]], 1u);
-            if (pos < CAP) {
-              reinterpret_cast<u64*>(stage16 + bkt[i] * 8)[pos] = rec[i];
-              pend &= ~(1u << i);
-            }
-          }
-        }
-        __syncthreads();
-        stage_flush<u64>(stage16, cnt, wpos, segb, part, false, est);
-        more = __syncthreads_or(pend != 0);
-      } while (more);
     }
-  }
-  stage_flush<u64>(stage16, cnt, wpos, segb, part, true, est);
+    pend = 0;
+#pragma unroll
+    for (int i = 0; i < RW; i++) {
+      rec[i] = 0;
+      bkt[i] = 0;
+      if (active && (L.Elo & vmask) == 0) {
+        u64 lo, hi;
+        kr.canonical(lo, hi);
+        const u64 g = mix42(lo);
+        rec[i] = (((w << 5) + (u64)(round * RW + i)) << 32) | (g & 0xffffffffULL);
+        bkt[i] = (u32)(g >> 32);
+        pend |= 1u << i;
+      }
+      if (active) {
+        kr.roll();
+        shr128(L.Elo, L.Ehi);
+      }
+    }
+    round++;
+    return true;
+  });
 }
 
 // ---- generic partition of plain u32 values by (v >> shift): histogram + scatter of (v & mask) ---------------------
@@ -124,20 +107,15 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
                                                                  u32 shift, const u32* __restrict__ seg_off,
                                                                  u32* __restrict__ out, EstSeg est) {
   const u64 n = *n_ptr;
-  constexpr u32 CAP = Stg<u32>::CAP;
-  constexpr u32 VR = 4;  // values per lane per round
+  constexpr int VR = 4;  // values per lane per round
   extern __shared__ __align__(16) u32 lds[];
-  uint4* stage16 = reinterpret_cast<uint4*>(lds);
-  u32* stage = lds;
-  u32* cnt = lds + P3_NB * 32;
-  u32* wpos = cnt + P3_NB;
-  u32* segb = wpos + P3_NB;
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
-    cnt[i] = 0;
-    wpos[i] = 0;
-    segb[i] = seg_base(seg_off, i, est);
-  }
-  __syncthreads();
+  const StageLds stg = stage_layout(lds);
+  stage_init(stg, seg_off, est);
+  StageCarry<u32> carry;
+  carry.has = false;
+  carry.par = 0;
+  carry.bkt = 0;
+  carry.rec = 0;
   u64 begin, end;
   u32_range(n, blockIdx.x, begin, end);
   const u32 mask = (1u << shift) - 1;
@@ -145,7 +123,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
     u32 rec[VR], bkt[VR];
     u32 pend = 0;
 #pragma unroll
-    for (u32 t = 0; t < VR; t++) {
+    for (int t = 0; t < VR; t++) {
       const u64 i = base + (u64)t * blockDim.x + threadIdx.x;
       rec[t] = 0;
       bkt[t] = 0;
@@ -156,24 +134,9 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
         pend |= 1u << t;
       }
     }
-    int more;
-    do {
-#pragma unroll
-      for (u32 t = 0; t < VR; t++) {
-        if (pend & (1u << t)) {
-          const u32 pos = atomicAdd(&cnt[bkt[t]], 1u);
-          if (pos < CAP) {
-            stage[bkt[t] * CAP + pos] = rec[t];
-            pend &= ~(1u << t);
-          }
-        }
-      }
-      __syncthreads();
-      stage_flush<u32>(stage16, cnt, wpos, segb, out, false, est);
-      more = __syncthreads_or(pend != 0);
-    } while (more);
+    stage_round<u32, VR>(stg, out, est, rec, bkt, pend, carry);
   }
-  stage_flush<u32>(stage16, cnt, wpos, segb, out, true, est);
+  stage_finish<u32>(stg, out, est, carry);
 }
 
 // ---- k_solid_slices: S[w] = valid21 bits of word w AND NOT the non-solid bits of this slice --------------------------

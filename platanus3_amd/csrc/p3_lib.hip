@@ -384,7 +384,7 @@ int part_local(p3_ctx* c, bool with_pos) {
   }
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
-  const size_t lds8 = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+  const size_t lds8 = (size_t)P3_STAGE_WORDS * 4;
   if (est) {
     // no histogram pass and no scan: fixed-stride segments; the scatter reports what it wrote
     if ((rc = fixed_segoff(c, segcap))) return rc;
@@ -528,7 +528,7 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
-  const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+  const size_t lds_sc = (size_t)P3_STAGE_WORDS * 4;
   // estimated mode needs the number of positions (or last pass's) on the host to size the segments
   const u64 n_est = c->spec ? c->hint_nsing : n_pos_bound;
   const bool est = est_mode(c) && (c->spec ? c->hint_nsing > 0 : true);
@@ -673,7 +673,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
     if ((rc = ensure(c, c->kpart, (est ? (u64)P3_NB * P3_NWG * segcap_k : max_records) * sizeof(REC)))) return rc;
     if ((rc = ensure(c, c->dkeys, (c->n_words * 32 + 1) * 8 * NW))) return rc;
-    const size_t lds_sc = ((size_t)P3_NB * 32 + 3 * P3_NB) * 4;
+    const size_t lds_sc = (size_t)P3_STAGE_WORDS * 4;
     if (est) {
       // estimated segment capacities: the scatter evaluates the gate itself (P, statistics) -- no histogram pass
       if ((rc = fixed_segoff(c, segcap_k))) return rc;
