@@ -74,8 +74,13 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "bloom_slices" 1 (default) = after dedup, probe positions are partitioned by bit-vector slice and OR-ed
  *                 in LDS (bloom_mode reads back 3); 0 = global atomicOr per probe (bloom_mode 2)
  *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 14; 2-word keys use 2 less)
+ *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
+ *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
+ *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 3x -- fewer bytes to
+ *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
+ *                 both forms record by record, so ranks need not agree.
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
- * "rs_log2", "distinct_kmers". */
+ * "rs_log2", "distinct_kmers", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 
@@ -168,7 +173,8 @@ int p3_reset_kernel_stats(p3_ctx* ctx);
  * all-gather; RCCL has no OR reduction).  The library does the compute; the HOST moves the bytes (RCCL
  * directly, or torch.distributed as platanus3_amd/pipeline.py does) between the device buffers below.
  *
- *   p3_mr_config -> p3_load_reads -> p3_mr_count_partition -> p3_mr_count_send_layout
+ *   p3_mr_config -> p3_load_reads -> p3_mr_count_partition (partition; optional local pre-aggregation, see
+ *   "mr_aggregate") -> p3_mr_count_send_layout
  *     [all-to-all of per-destination record counts, then of the blobs and their descriptor rows]
  *   -> p3_mr_count_recv_alloc (before the data all-to-all) -> p3_mr_count_owned(sbits)
  *     [all-reduce MAX of `overflowed`: if set, every rank repeats with sbits+1; all-reduce MAX of max_solid_sb]

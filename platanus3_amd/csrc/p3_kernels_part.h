@@ -24,6 +24,8 @@
 #define P3_NB (1u << P3_PBITS)  // physical buckets
 #define P3_CAP 32u              // staged records per bucket (two 64-byte chunks)
 #define P3_NWG 256u             // workgroups of the hist/scatter kernels (static word partition)
+#define P3_K2_WEIGHTED 1u       // k_part_count mode bits (multi-rank pre-aggregation)
+#define P3_K2_AGG_OUT 2u
 #define P3_PART_THREADS 1024
 #define P3_TS_LOG2_MAX 14       // LDS count table: 16384 slots x (4 B remainder + 4 B count) = 128 KiB
 #define P3_EMPTY32 0xffffffffu
@@ -295,8 +297,18 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                      u64* __restrict__ gstats, u64* __restrict__ tpairs,
                                                      u32* __restrict__ singles,
-                                                     u64* __restrict__ sing_cursor, u32 dbg) {
+                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
+  // mode & P3_K2_WEIGHTED (POS only): the records are locally pre-aggregated -- bit 63 set = "this key occurred
+  // (bits 62..32) times at the sender", clear = one instance at window position (bits 62..32).
+  // mode & P3_K2_AGG_OUT (POS only): emit such records instead of the table (the sender side of the above).
+  const bool weighted = POS && (mode & P3_K2_WEIGHTED);
+  auto weight_of = [&](REC item) -> u32 {
+    if constexpr (POS) {
+      if (weighted && ((u64)item >> 63)) return (u32)((u64)item >> 32) & 0x7fffffffu;
+    }
+    return 1u;
+  };
   constexpr u32 VCAP = POS ? P3_VCAP_POS : P3_VALID_CAP;
   constexpr u32 QCAP = POS ? P3_WQ_CAP_POS : P3_WQ_CAP;
   constexpr int NBATCH = POS ? 8 : 16;  // records per reader batch
@@ -370,7 +382,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         }
       }
       if (old == P3_EMPTY32 || old == rem) {
-        atomicAdd(&tcnt[slot], 1u);
+        atomicAdd(&tcnt[slot], weight_of(item));
         placed = true;
         break;
       }
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           const int i = g0 + t;
           const bool mine = (act & (1u << i)) && ((((u32)r[i] >> rem_bits) & sub_mask) == subsel);
           const bool hit = mine && cur[t] == rem[t];
-          if (hit) atomicAdd(&tcnt[slot[t]], 1u);
+          if (hit) atomicAdd(&tcnt[slot[t]], weight_of(r[i]));
           const bool miss = mine && !hit;
           const unsigned long long bal = __ballot(miss);
           if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = r[i];
@@ -440,6 +452,22 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   __syncthreads();
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
   if (dbg & 4) return;  // timing experiment: no emission
+  if constexpr (POS) {
+    if (mode & P3_K2_AGG_OUT) {
+      // one record per distinct key, in place over this sub-bucket's first-instance pairs; k_agg_compact
+      // moves them into the send partition once every sub-bucket's count is known
+      const u32 nd = s_ndist;
+      for (u32 t = threadIdx.x; t < nd; t += blockDim.x) {
+        const u64 pr = tpairs[tbase + t];
+        const u32 slot = (u32)(pr >> 32) & (TS - 1);
+        const u32 cnt = tcnt[slot];
+        const u32 hi = cnt == 1 ? ((u32)pr & 0x7fffffffu) : (0x80000000u | (cnt < 0x7fffffffu ? cnt : 0x7fffffffu));
+        tpairs[tbase + t] = ((u64)hi << 32) | ((u64)subsel << rem_bits) | tkey[slot];
+      }
+      if (threadIdx.x == 0) sb_info[sb] = make_uint4(0u, nd, 0u, 0u);
+      return;
+    }
+  }
   u32 my_solid = 0, my_max = 0, my_single = 0;
   for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {  // TS is a multiple of the block size or smaller than it
     const u32 i = i0 + threadIdx.x;

@@ -259,3 +259,24 @@ __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 
   if (threadIdx.x == 0 && blk) atomicAdd((unsigned long long*)out, blk);
 }
 
+// ---- sender-side pre-aggregation (multi-rank): k_part_count in P3_K2_AGG_OUT mode leaves one record per distinct
+// local key in its sub-bucket's window of the pair buffer; these two kernels turn that into a partition in the
+// standard format (segment j < 2^sbits of bucket b = sub-bucket j; the other segments are empty).
+__global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P3_NB * P3_NWG) return;
+  const u32 pb = i / P3_NWG, j = i % P3_NWG;
+  ghist[i] = j < (1u << sbits) ? sb_info[(pb << sbits) + j].y : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
+                                                     const u32* __restrict__ seg_off, u32 sbits, u32 ts_log2,
+                                                     u64* __restrict__ out) {
+  const u32 sb = blockIdx.x;
+  const u32 pb = sb >> sbits, sub = sb & ((1u << sbits) - 1);
+  const u32 n = sb_info[sb].y;
+  const u64* src = pairs + ((u64)sb << ts_log2);
+  u64* dst = out + seg_off[pb * P3_NWG + sub];
+  for (u32 t = threadIdx.x; t < n; t += blockDim.x) dst[t] = src[t];
+}
+

@@ -85,6 +85,11 @@ struct p3_ctx {
   bool mr_partitioned = false;
   bool protocol = false;  // p3_mr_config was called: blobs must be contiguous, so segment offsets stay exact
   bool reparted = false;  // the received records have been split into 1024 local cells (n_ranks > 1)
+  bool rx_weighted = false;  // received records may be pre-aggregated (bit 63 = count form): see k_part_count
+  int agg_opt = 1;
+  bool agg = false;          // this rank's send partition is pre-aggregated (apart)
+  DevBuf apart;
+  u64 agg_padded = 0, agg_distinct_est = 0;
   u32 xbits = 0;
   DevBuf lpart;
   // coverage gate: 1 = probe the solid-key regions per window, 2 = return path (non-solid positions come back
@@ -464,14 +469,15 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt);
+               (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
+               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -584,6 +590,67 @@ int set_rx_local(p3_ctx* c) {
   c->rx_segoff = c->seg_off.p;
   c->rx_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;  // bound on real records (sizes the outputs)
   c->reparted = false;
+  c->rx_weighted = false;
+  return P3_OK;
+}
+
+// Sender-side pre-aggregation for the multi-rank exchange: count this rank's own partition once (same kernel as
+// the owners use) and replace it by ONE record per distinct local key -- (position | low bits of g) for a key seen
+// once, (bit 63 | local count | low bits of g) otherwise.  Under 30x coverage that is ~7x fewer records to move
+// and to count at the owner; the owners' result is unchanged (sum of local counts; a key is non-solid exactly when
+// its only record is a position record).  Returns with c->agg = false (raw exchange) if a table overflowed.
+int agg_local(p3_ctx* c) {
+  int rc;
+  c->agg = false;
+  if (!c->part_pos) return P3_OK;
+  if ((rc = set_rx_local(c))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  const u32 ts_log2 = (u32)c->ts_log2_opt;
+  const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
+  // How many distinct keys does this rank hold?  That depends on the coverage of ITS reads (30x / n_ranks in the
+  // sharded benchmark), so it is measured: the aggregation kernel is run on buckets 0..7 only, at the finest
+  // split (which cannot overflow), and the count is scaled up.  Few repeats => the aggregation would cost more
+  // than the bytes it saves: keep the raw records.
+  const u32 sample_sbits = 4, sample_buckets = 8;
+  if ((rc = ensure(c, c->tpos, (((size_t)P3_NB << 5) << ts_log2) * 8))) return rc;
+  if ((rc = ensure(c, c->sb_info, ((size_t)P3_NB << 5) * 16))) return rc;
+  u64 h[6];
+  HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
+             (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
+             sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
+             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+  HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
+  const u64 records = h[5];  // this rank's windows (left by the partition step)
+  c->agg_distinct_est = distinct_est;
+  if (h[3] || (c->agg_opt != 2 && records < 3 * distinct_est)) return P3_OK;
+  u32 sbits = 1;
+  while (sbits < 5 && distinct_est / ((u64)P3_NB << sbits) > 11000) sbits++;
+  for (;; sbits++) {
+    if (sbits > 5) return P3_OK;
+    const u32 nsb = P3_NB << sbits;
+    HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
+               (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
+               (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
+               (u32)P3_K2_AGG_OUT);
+    HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!h[3]) break;
+  }
+  HIPCHK(c, hipMemsetAsync(st + 28, 0, 3 * 8, c->stream));
+  LAUNCH(c, "k_agg_hist", k_agg_hist, P3_NB * P3_NWG / 256, 256, (const uint4*)c->sb_info.p, sbits, (u32*)c->ghist.p);
+  if ((rc = do_scan(c, st + 28))) return rc;
+  u64 tot[3];
+  HIPCHK(c, hipMemcpyAsync(tot, st + 28, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((rc = ensure(c, c->apart, (tot[1] + 16) * 8))) return rc;
+  LAUNCH(c, "k_agg_compact", k_agg_compact, P3_NB << sbits, 256, (const u64*)c->tpos.p, (const uint4*)c->sb_info.p,
+         (const u32*)c->seg_off.p, sbits, ts_log2, (u64*)c->apart.p);
+  c->agg = true;
+  c->agg_padded = tot[1];
   return P3_OK;
 }
 
@@ -1033,6 +1100,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "mr_aggregate") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
+    c->agg_opt = (int)value;
   } else if (n == "ts_log2") {
     if (value < 4 || value > P3_TS_LOG2_MAX) return fail(c, P3_EBADARG, "ts_log2 must be in [4,%d]", P3_TS_LOG2_MAX);
     c->ts_log2_opt = (int)value;
@@ -1053,6 +1123,9 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
+  else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
+  else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
+  else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);
   else return fail(c, P3_EBADARG, "unknown info %s", name);
   return P3_OK;
 }
@@ -1124,7 +1197,15 @@ int p3_mr_count_partition(p3_ctx* c) {
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   const bool with_pos = c->gate_mode_opt != 1 && retgate_applicable(c);
   if ((rc = part_local(c, with_pos))) return rc;
+  u64 nwin = 0;  // the local window count is taken before the aggregation reuses the descriptor tables
+  HIPCHK(c, hipMemcpyAsync(&nwin, (const u64*)c->dstats.p + 5, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->cstats.n_windows = nwin;
+  c->agg = false;
+  if (c->n_ranks > 1 && c->agg_opt) {
+    if ((rc = agg_local(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   c->mr_partitioned = true;
   c->counted = false;
   return P3_OK;
@@ -1135,7 +1216,7 @@ int p3_mr_count_send_layout(p3_ctx* c, p3_mr_send_layout* out) {
   if (!c->mr_partitioned) return fail(c, P3_ESTATE, "p3_mr_count_partition first");
   HIPCHK(c, hipSetDevice(c->device));
   const u32 rows = P3_NB / c->n_ranks;
-  out->d_part = c->part_pos ? c->part8.p : c->part.p;
+  out->d_part = c->agg ? c->apart.p : (c->part_pos ? c->part8.p : c->part.p);
   out->rec_bytes = c->part_pos ? 8 : 4;
   out->d_ghist = c->ghist.p;
   out->d_segoff = c->seg_off.p;
@@ -1147,9 +1228,8 @@ int p3_mr_count_send_layout(p3_ctx* c, p3_mr_send_layout* out) {
     out->rec_off[d] = v;
   }
   u64 tot[3];
-  HIPCHK(c, hipMemcpy(tot, (const u64*)c->dstats.p + 5, sizeof tot, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(tot, (const u64*)c->dstats.p + (c->agg ? 28 : 5), sizeof tot, hipMemcpyDeviceToHost));
   out->rec_off[c->n_ranks] = tot[1];
-  c->cstats.n_windows = tot[0];
   return P3_OK;
 }
 
@@ -1176,6 +1256,7 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
   c->rx_segoff = c->rx_segoff_buf.p;
   c->rx_records = roff[c->n_ranks];
   c->reparted = false;
+  c->rx_weighted = c->part_pos;  // any source may have pre-aggregated; raw records decode as weight 1
   *d_rpart = c->rx_part;
   *d_rghist = c->rx_ghist;
   *d_rsegoff = c->rx_segoff;
@@ -1185,6 +1266,14 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
 int p3_mr_initial_sbits(p3_ctx* c, uint32_t* sbits) {
   if (!c || !sbits) return P3_EBADARG;
   // after the owner-side re-partition a cell holds 1/1024 of what this rank RECEIVED
+  if (c->agg && c->rx_records) {
+    // pre-aggregated input: at most one record per (source, key); keys shared by two or more sources are the
+    // common case (they are what makes a key solid), hence the factor 2.  A wrong guess costs one repeat.
+    u32 sb = 1;
+    while (sb < 5 && c->rx_records / ((u64)P3_NB << sb) > 24000) sb++;
+    *sbits = sb;
+    return P3_OK;
+  }
   *sbits = initial_sbits(c->rx_records ? c->rx_records : c->n_words * 32);
   return P3_OK;
 }

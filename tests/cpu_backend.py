@@ -36,9 +36,12 @@ def unmix42(g):
 
 
 class CpuBackend:
-    def __init__(self, oracle, gate=2):
+    def __init__(self, oracle, gate=2, aggregate=True):
         self.o = oracle
         self.gate = gate   # 2 = return path (records carry positions), 1 = solid-region table
+        # sender-side pre-aggregation (gate 2 only), as p3_mr_count_partition does: one record per distinct local
+        # key -- (position | g low) for a key seen once, (bit 63 | local count | g low) otherwise
+        self.aggregate = aggregate and gate == 2
         self.timing = {}
 
     def gate_mode(self):
@@ -70,7 +73,14 @@ class CpuBackend:
         g = mix42(keys)
         pb = (g >> np.uint64(32)).astype(np.int64)
         order = np.argsort(pb, kind="stable")
-        if self.gate == 2:
+        if self.gate == 2 and self.aggregate:
+            self.win_keys = keys
+            self.win_pos = self._window_positions()
+            ug, first, cnt = np.unique(g, return_index=True, return_counts=True)
+            hi = np.where(cnt == 1, self.win_pos[first], np.uint64(0x80000000) | cnt.astype(np.uint64)).astype(np.uint64)
+            rec = (hi << np.uint64(32)) | (ug & np.uint64(0xffffffff))   # ug is sorted, hence bucket-ordered
+            pb = (ug >> np.uint64(32)).astype(np.int64)
+        elif self.gate == 2:
             self.win_keys = keys
             self.win_pos = self._window_positions()
             rec = ((self.win_pos << np.uint64(32)) | (g & np.uint64(0xffffffff)))[order]
@@ -114,7 +124,7 @@ class CpuBackend:
         gh = self.rghist.reshape(W, rows, NWG)
         so = self.rsegoff.reshape(W, rows, NWG)
         roff = np.concatenate([[0], np.cumsum(self.recv_records)])
-        gs, srcs, poss = [], [], []
+        gs, srcs, poss, wts = [], [], [], []
         for s in range(W):
             sbase = int(so[s, 0, 0])
             for r in range(rows):
@@ -124,8 +134,12 @@ class CpuBackend:
                     gs.append((np.uint64(self.rank * rows + r) << np.uint64(32)) | (recs & np.uint64(0xffffffff)))
                     srcs.append(np.full(recs.size, s, np.int64))
                     poss.append((recs >> np.uint64(32)).astype(np.uint32))
+                    multi = (recs >> np.uint64(63)).astype(bool) if self.gate == 2 else np.zeros(recs.size, bool)
+                    wts.append(np.where(multi, (recs >> np.uint64(32)) & np.uint64(0x7fffffff), np.uint64(1)).astype(np.int64))
         g = np.concatenate(gs) if gs else np.zeros(0, np.uint64)
-        ug, inv, cnt = np.unique(g, return_inverse=True, return_counts=True)
+        ug, inv = np.unique(g, return_inverse=True)
+        w = np.concatenate(wts) if wts else np.zeros(0, np.int64)
+        cnt = np.bincount(inv, weights=w, minlength=ug.size).astype(np.int64)   # weight 1 = a raw / position record
         if self.gate == 2:
             single = cnt[inv] == 1   # instances that are the only one of their key
             src = np.concatenate(srcs) if srcs else np.zeros(0, np.int64)

@@ -253,10 +253,12 @@ def test_config2_full_size_against_reference_checksums(ctx):
         assert ctx.bloom_query(np.minimum(samp, rc)).all()
 
 
-@pytest.mark.parametrize("world,k,gate", [(2, 31, 2), (4, 31, 2), (4, 41, 1), (8, 25, 2)])
-def test_multirank_loopback(oracle, world, k, gate):
+@pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3)])
+def test_multirank_loopback(oracle, world, k, gate, agg):
     """The REAL multi-rank protocol (HIP kernels, n_ranks = 2/4/8) on one GPU: `world` contexts driven by threads,
-    exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads."""
+    exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads.
+    agg: 1 = senders pre-aggregate their 21-mer records (forced), 0 = raw instance records, 2 = even ranks only,
+    3 = the library decides from its sampled estimate of the rank's distinct keys (the default)."""
     import threading
     from loopback_comm import LoopbackWorld
     from platanus3_amd.pipeline import Pipeline
@@ -272,9 +274,13 @@ def test_multirank_loopback(oracle, world, k, gate):
             bb, oo = synth.reads(seed=41, total_reads=n_reads, first_read=r * per, n_reads=per, read_len=150)
             pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
             pipe.ctx.set_option("gate_mode", gate)
+            want_agg = agg == 1 or (agg == 2 and r % 2 == 0)
+            pipe.ctx.set_option("mr_aggregate", 1 if agg == 3 else (2 if want_agg else 0))
             pipe.load_reads(bb, oo, min_len=k)
             pipe.run_pass(k, m, H)
             c = pipe.ctx
+            if agg != 3:
+                assert c.get_info("mr_aggregated") == (1 if (want_agg and gate == 2) else 0)
             c.k, c.m, c.H = k, m, H
             keys, counts = c.export_counts()
             results[r] = (keys.copy(), counts.copy(), c.export_bloom(), [capi.decode_key(x, k) for x in c.export_seeds()])

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, n_reads, tmpdir, gate):
+def _worker(rank, world, port, k, n_reads, tmpdir, gate, agg):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,9 @@ def _worker(rank, world, port, k, n_reads, tmpdir, gate):
         per = n_reads // world
         b, offs = synth.reads(seed=5, total_reads=n_reads, first_read=rank * per, n_reads=per, read_len=150)
         m, H = o.estimate_bloom(n_reads * 150, k)
-        be = CpuBackend(o, gate=gate)
+        # agg: 1 = every rank pre-aggregates what it sends, 0 = raw instance records, 2 = mixed (even ranks only):
+        # the owners decode both forms record by record
+        be = CpuBackend(o, gate=gate, aggregate=(agg == 1) or (agg == 2 and rank % 2 == 0))
         pipe = Pipeline(rank=rank, world=world, backend=be)
         pipe.load_reads(b, offs, min_len=k)
         pipe.run_pass(k, m, H)
@@ -53,12 +55,13 @@ def _worker(rank, world, port, k, n_reads, tmpdir, gate):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,gate", [(2, 31, 2), (4, 25, 2), (2, 47, 1), (4, 31, 1)])
-def test_sharded_pass_equals_single_rank(tmp_path, oracle, world, k, gate):
+@pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 25, 2, 1), (2, 31, 2, 0), (4, 41, 2, 2), (2, 47, 1, 0),
+                                              (4, 31, 1, 0)])
+def test_sharded_pass_equals_single_rank(tmp_path, oracle, world, k, gate, agg):
     import platanus3_amd.synth as synth
     n_reads = 1200
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, k, n_reads, str(tmp_path), gate), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, k, n_reads, str(tmp_path), gate, agg), nprocs=world, join=True)
     b, offs = synth.reads(seed=5, total_reads=n_reads, read_len=150)
     m, H = oracle.estimate_bloom(n_reads * 150, k)
     ekeys, ecounts = oracle.count_short((b, offs), min_len=k)

@@ -1,13 +1,16 @@
 """Per-rank kernel times of the multi-rank protocol at weak scale, emulated on ONE GPU (N contexts, threads).
 Ranks share the GPU, so absolute times are inflated; the point is to spot work that grows with N."""
 import sys, threading, json
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import platanus3_amd.synth as synth
 from platanus3_amd.pipeline import Pipeline
 from loopback_comm import LoopbackWorld
 from bench import bloom_sizing
 
 world = int(sys.argv[1]); per = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+agg = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 k = 31
 total = per * world
 m, H = bloom_sizing(total * 150, k)
@@ -16,6 +19,7 @@ out = [None] * world
 def worker(r):
     b, o = synth.reads(seed=2, total_reads=total, first_read=r * per, n_reads=per, read_len=150)
     pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
+    pipe.ctx.set_option('mr_aggregate', agg)
     pipe.load_reads(b, o, min_len=k)
     pipe.run_pass(k, m, H)
     if r == 0:
@@ -26,6 +30,8 @@ def worker(r):
         out[0] = {n: round(s["total_ms"], 3) for n, s in sorted(pipe.ctx.kernel_stats().items())}
         out[0]["_sbits"] = pipe.ctx.get_info("sbits"); out[0]["_ksbits"] = pipe.ctx.get_info("ksbits")
         out[0]["_distinct_k"] = pipe.ctx.get_info("distinct_kmers")
+        out[0]["_send_records"] = pipe.ctx.get_info("mr_send_records")
+        out[0]["_sum_ms"] = round(sum(v for n, v in out[0].items() if n.startswith("k_")), 3)
 th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
 [t.start() for t in th]; [t.join() for t in th]
 print(json.dumps(out[0]))
