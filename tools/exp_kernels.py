@@ -10,8 +10,12 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 31
 b, o = synth.reads(seed=2, total_reads=1_000_000, read_len=150)
 m, H = bloom_sizing(int(b.size), k)
 c = capi.Context(0)
+for a in sys.argv[2:]:
+    if '=' in a:
+        n, v = a.split('=')
+        c.set_option(n, int(v))
 c.load_reads(b, o, k)
-quick = len(sys.argv) > 2
+quick = 'quick' in sys.argv
 for _ in range(1 if quick else 3):
     c.run_pass(k, m, H)
 if quick:

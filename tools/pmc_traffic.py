@@ -1,0 +1,35 @@
+"""FETCH_SIZE / WRITE_SIZE counter CSVs (one rocprofv3 --pmc pass each) -> per-launch HBM bytes per kernel.
+KB -> bytes x1024; FETCH_SIZE is doubled for the kernels whose reads are wide coalesced 16-B-per-lane streams
+(gfx950 reports half of those bytes, MI355X_MICROARCH.md, HBM section); other access shapes are left as reported."""
+import sys, csv, glob, json, collections
+
+WIDE_READERS = {"k_pack", "k_part_count", "k_kmer_dedup", "k_bloom_slices", "k_solid_slices"}
+
+
+def short(name):
+    n = name.replace("void ", "")
+    for sep in ("<", "("):
+        n = n.split(sep)[0]
+    return n
+
+
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            cnt[k][row["Counter_Name"]] += 1
+out = {"_method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `bench.py --steps 3 --warmup 1`; "
+                  "per-launch averages; KB -> bytes x1024; FETCH_SIZE doubled for kernels whose reads are wide coalesced "
+                  "16-B-per-lane streams (gfx950 reports 1/2 of those bytes, MI355X_MICROARCH.md section HBM); other access "
+                  "shapes uncalibrated and left as reported", "kernels": {}}
+for k in sorted(tot):
+    f = tot[k].get("FETCH_SIZE", 0.0) / max(1, cnt[k].get("FETCH_SIZE", 0)) * 1024.0
+    w = tot[k].get("WRITE_SIZE", 0.0) / max(1, cnt[k].get("WRITE_SIZE", 0)) * 1024.0
+    dbl = k in WIDE_READERS
+    fc = f * 2 if dbl else f
+    out["kernels"][k] = {"fetch_bytes_reported": f, "fetch_doubled": dbl, "fetch_bytes_corrected": fc, "write_bytes": w,
+                         "hbm_bytes_per_launch": fc + w}
+print(json.dumps(out, indent=1, sort_keys=True))
