@@ -60,13 +60,21 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       uint4 v[4];
       u32 jj[4];
       u32 nval[4];
+      // all four table bytes first (one LDS round trip, clamped index instead of a branch), then the four loads
+      // back to back; a vector is fetched only if its chunk holds a record at or beyond the vector's first slot
+      // (gaps between estimated-capacity segments and segment tails cost no memory traffic)
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         jj[u] = j0 + u * B;
-        // a vector is fetched only if its chunk holds a record at or beyond the vector's first slot (gaps between
-        // estimated-capacity segments and segment tails cost no memory traffic)
-        nval[u] = (jj[u] < nvec) ? (u32)valid[jj[u] / VPC] : 0u;
-        v[u] = (nval[u] > (jj[u] % VPC) * RPV) ? vec[jj[u]] : make_uint4(0, 0, 0, 0);
+        const u32 ci = jj[u] / VPC;
+        nval[u] = (u32)valid[ci < VCAP ? ci : VCAP - 1];
+      }
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        if (jj[u] >= nvec) nval[u] = 0;
+        // branch-free: a lane with nothing to fetch re-reads the window's first vector (one broadcast line)
+        // and its records stay masked out by `act`
+        v[u] = vec[(nval[u] > (jj[u] % VPC) * RPV) ? jj[u] : 0u];
       }
       REC recs[4 * RPV];
       u32 act = 0;

@@ -549,16 +549,6 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
     slow_insert(lo, hi, slot);
   };
   bucket_for_each<REC, P3_VCAP_POS>(part, seg_off, ghist, pb, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
-    if (dbg & 2) {  // timing experiment: read only
-      u64 x = 0;
-#pragma unroll
-      for (int i = 0; i < NBATCH; i++) {
-        if constexpr (NW == 1) x ^= r[i];
-        else x ^= r[i].lo;
-      }
-      if (x == 0x1234567 && act == 77) sc[7] = 1;
-      return;
-    }
 #pragma unroll
     for (int g0 = 0; g0 < NBATCH; g0 += G) {
       u64 lo[G], hi[G], cur_lo[G], cur_hi[G];
@@ -593,7 +583,6 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
         qn += (u32)__popcll(bal);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      if (dbg & 1) qn = 0;  // timing experiment: drop the misses
       while (qn >= 64) {
         qn -= 64;
         const REC it = wq[qn + lane_id];

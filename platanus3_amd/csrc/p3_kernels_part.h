@@ -402,13 +402,6 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     const REC* part_src = xbits ? part : part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
     const u32 segs = xbits ? P3_NWG / n_src : P3_NWG;
     bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
-      if (dbg & 2) {  // timing experiment: read only
-        u64 x = 0;
-#pragma unroll
-        for (int i = 0; i < NBATCH; i++) x ^= (u64)r[i];
-        if (x == 0x1234567 && act == 77) s_ovf = 1;
-        return;
-      }
 #pragma unroll
       for (int g0 = 0; g0 < NBATCH; g0 += G) {
         u32 rem[G], slot[G], cur[G];
@@ -430,7 +423,6 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           qn += (u32)__popcll(bal);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (dbg & 1) qn = 0;  // timing experiment: drop the misses
         while (qn >= 64) {
           qn -= 64;
           slow_insert(wq[qn + lane]);
@@ -451,7 +443,6 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   }
   __syncthreads();
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
-  if (dbg & 4) return;  // timing experiment: no emission
   if constexpr (POS) {
     if (mode & P3_K2_AGG_OUT) {
       // one record per distinct key, in place over this sub-bucket's first-instance pairs; k_agg_compact
