@@ -55,33 +55,44 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
     // that the consumer can issue its LDS lookups for all of them before using any (LDS latency chains,
     // not HBM, bound these kernels at 4 waves per SIMD).
     const u32 B = blockDim.x;
-    for (u32 jb = 0; jb < nvec; jb += 4 * B) {  // uniform trip count: consumers use wave-wide ballots
+    // all four table bytes first (one LDS round trip, clamped index instead of a branch), then the four loads
+    // back to back; a vector is fetched only if its chunk holds a record at or beyond the vector's first slot
+    // (gaps between estimated-capacity segments and segment tails cost no memory traffic): a lane with nothing
+    // to fetch re-reads the window's first vector (one broadcast line) and its records stay masked out by `act`
+    auto fetch = [&](u32 jb, uint4 (&v)[4], u32 (&nval)[4]) {
       const u32 j0 = jb + threadIdx.x;
-      uint4 v[4];
-      u32 jj[4];
-      u32 nval[4];
-      // all four table bytes first (one LDS round trip, clamped index instead of a branch), then the four loads
-      // back to back; a vector is fetched only if its chunk holds a record at or beyond the vector's first slot
-      // (gaps between estimated-capacity segments and segment tails cost no memory traffic)
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
-        jj[u] = j0 + u * B;
-        const u32 ci = jj[u] / VPC;
+        const u32 ci = (j0 + u * B) / VPC;
         nval[u] = (u32)valid[ci < VCAP ? ci : VCAP - 1];
       }
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
-        if (jj[u] >= nvec) nval[u] = 0;
-        // branch-free: a lane with nothing to fetch re-reads the window's first vector (one broadcast line)
-        // and its records stay masked out by `act`
-        v[u] = vec[(nval[u] > (jj[u] % VPC) * RPV) ? jj[u] : 0u];
+        const u32 j = j0 + u * B;
+        if (j >= nvec) nval[u] = 0;
+        v[u] = vec[(nval[u] > (j % VPC) * RPV) ? j : 0u];
       }
+    };
+    // software pipeline: the loads of batch i+1 are in flight while the consumer works on batch i
+    uint4 vn[4];
+    u32 nvn[4];
+    if (nvec) fetch(0, vn, nvn);
+    for (u32 jb = 0; jb < nvec; jb += 4 * B) {  // uniform trip count: consumers use wave-wide ballots
+      const u32 j0 = jb + threadIdx.x;
+      uint4 v[4];
+      u32 nval[4];
+#pragma unroll
+      for (u32 u = 0; u < 4; u++) {
+        v[u] = vn[u];
+        nval[u] = nvn[u];
+      }
+      if (jb + 4 * B < nvec) fetch(jb + 4 * B, vn, nvn);
       REC recs[4 * RPV];
       u32 act = 0;
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         const u32 nvalid = nval[u];
-        const u32 first = (jj[u] % VPC) * RPV;
+        const u32 first = ((j0 + u * B) % VPC) * RPV;
         if constexpr (sizeof(REC) == 4) {
           recs[4 * u + 0] = v[u].x;
           recs[4 * u + 1] = v[u].y;
