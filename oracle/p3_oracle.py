@@ -262,8 +262,40 @@ class RefLib:
         L.p3ref_hash_words.argtypes = [_u64p, C.c_uint64, C.c_int, _u64p, _u64p, _u64p]
         L.p3ref_bloom_query.argtypes = [_u64p, C.c_uint64, C.c_int, _u64p, C.c_uint64, C.c_int, _u8p]
         L.p3ref_encode21.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_char_p, C.c_char_p]
+        L.p3ref_open_file.restype = C.c_void_p
+        L.p3ref_open_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+        L.p3ref_dump_reads.restype = C.c_uint64
+        L.p3ref_dump_reads.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.p3ref_run_loaded.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_int)]
         L.p3ref_rmq.restype = C.c_uint64
         L.p3ref_rmq.argtypes = [_u64p, C.c_uint64, C.c_int, _u64p]
+
+    def load_file(self, path, k):
+        """The real ReadFile(options) + LoadFile() on `path` -> dict(all_bases, suffix_ok, entries=[(name, seq) sorted])."""
+        ok = C.c_int()
+        h = self.lib.p3ref_open_file(path.encode(), k, C.byref(ok))
+        try:
+            need = self.lib.p3ref_dump_reads(h, None, 0)
+            buf = C.create_string_buffer(max(1, need))
+            self.lib.p3ref_dump_reads(h, buf, need)
+            lines = buf.raw[:need].split(b"\n")[:-1] if need else []
+            entries = [(lines[i], lines[i + 1]) for i in range(0, len(lines), 2)]
+            return dict(all_bases=int(self.lib.p3ref_all_bases(h)), suffix_ok=int(ok.value), entries=entries)
+        finally:
+            self.lib.p3ref_close(h)
+
+    def run_file(self, path, k, workdir, m_in=0, threads=1):
+        """main()'s flow on a file (load, EstimateBloomfilter, Assemble<B>) -> (gfa text, m, H)."""
+        ok = C.c_int()
+        h = self.lib.p3ref_open_file(path.encode(), k, C.byref(ok))
+        try:
+            m, H = C.c_uint64(), C.c_int()
+            rc = self.lib.p3ref_run_loaded(h, k, m_in, threads, workdir.encode(), C.byref(m), C.byref(H))
+            assert rc == 0, rc
+            return open(os.path.join(workdir, "de_bruijn_graph.gfa")).read(), m.value, H.value
+        finally:
+            self.lib.p3ref_close(h)
 
     def estimate_bloom(self, all_bases, k, m_in=0):
         m, H = C.c_uint64(), C.c_int()

@@ -29,6 +29,7 @@
 #include "/root/reference/src/Logging.cpp"
 #undef private
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
@@ -246,6 +247,54 @@ int p3ref_assemble(void* h, int k, uint64_t m, int H, int threads, const char* w
 #undef X
     default: return 2;
   }
+}
+
+// The real loader (ReadFile ctor + LoadFile, src/Load.cpp:23-103) on a file.  Returns a session like p3ref_open;
+// *err = ReadFile::error_code is NOT read (it is uninitialised unless the suffix check fails, src/Load.cpp:27-29):
+// the suffix verdict is recomputed here.  Suffix must be "fasta"/"fastq" for the reference to proceed in main().
+void* p3ref_open_file(const char* path, int k, int* suffix_ok) {
+  Session* s = new Session();
+  s->options.readfile_name = path;
+  s->options.kmer_length = k;
+  s->logging.log_file = "/dev/null";
+  s->reads = new ReadFile(s->options);
+  *suffix_ok = (s->reads->file_type == "fasta" || s->reads->file_type == "fastq") ? 1 : 0;
+  s->reads->LoadFile();
+  return s;
+}
+
+// ReadSet dump: for every entry, name line then sequence line, entries sorted by name (neither string can hold a
+// newline: both come from getline).  Returns the number of bytes needed; writes at most cap.
+uint64_t p3ref_dump_reads(void* h, char* out, uint64_t cap) {
+  Session* s = (Session*)h;
+  std::vector<const std::pair<const std::string, std::string>*> v;
+  for (const auto& kv : s->reads->reads) v.push_back(&kv);
+  std::sort(v.begin(), v.end(), [](auto a, auto b) { return a->first < b->first; });
+  uint64_t need = 0;
+  for (auto e : v) need += e->first.size() + e->second.size() + 2;
+  if (need > cap) return need;
+  uint64_t j = 0;
+  for (auto e : v) {
+    std::memcpy(out + j, e->first.data(), e->first.size());
+    j += e->first.size();
+    out[j++] = '\n';
+    std::memcpy(out + j, e->second.data(), e->second.size());
+    j += e->second.size();
+    out[j++] = '\n';
+  }
+  return need;
+}
+
+// main()'s sequence after the load (main.cpp:20-28): EstimateBloomfilter, then Assemble<B> with the options'
+// own (m, H); m_in = 0 means "no -m given".  The GFA lands in <workdir>/de_bruijn_graph.gfa.
+int p3ref_run_loaded(void* h, int k, uint64_t m_in, int threads, const char* workdir, uint64_t* m_used, int* H_used) {
+  Session* s = (Session*)h;
+  s->options.filter_size = m_in;
+  s->options.threads_num = threads;
+  s->options.EstimateBloomfilter(s->reads->all_bases, s->logging);
+  *m_used = s->options.filter_size;
+  *H_used = s->options.num_hashes;
+  return p3ref_assemble(h, k, s->options.filter_size, s->options.num_hashes, threads, workdir);
 }
 
 // Known-answer primitives on one k-mer string (E1,E2,E4,E5,H1,H2,B1).

@@ -21,12 +21,17 @@
 #ifndef PLATANUS3_SHIM_HPP
 #define PLATANUS3_SHIM_HPP
 
+#include <unistd.h>
+
 #include <array>
 #include <bitset>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <functional>
+#include <iostream>
 #include <mutex>
 #include <set>
 #include <stdexcept>
@@ -104,13 +109,144 @@ struct Session {
 
 }  // namespace p3shim
 
-// ---- ReadFile: the part of src/Load.cpp:6-21 the path uses ----------------------------------------------------
+// ---- Options: src/Options.cpp:7-68 (same members, defaults, option letters and sizing arithmetic) ---------------------
+// (define PLATANUS3_SHIM_CORE_ONLY to keep the reference's own Options.cpp / Assemble.cpp / ShowInfo.cpp instead)
+#ifndef PLATANUS3_SHIM_CORE_ONLY
+typedef int Error;  // src/common.h:24
+class Options {
+ public:
+  std::string readfile_name;
+  uint64_t filter_size = 0;   // -m; 0 = size it from the input (EstimateBloomfilter)
+  uint8_t num_hashes = 10;    // stays 10 when -m is given
+  int threads_num = 8;        // -t; the device graph stage does not depend on it
+  uint32_t kmer_length = 25;  // -k
+  uint32_t shortk_length = 21;
+  double error_rate = 0.0005;
+
+  // "i:m:k:t:" (src/Options.cpp:25); an unknown letter logs "Invalid option" and returns false
+  bool Parse(int argc, char** argv, Logging& logging) {
+    optind = 1;
+    for (int opt; (opt = getopt(argc, argv, "i:m:k:t:")) != -1;) {
+      if (opt == 'i') readfile_name = optarg;
+      else if (opt == 'm') filter_size = (uint64_t)std::stoll(optarg);
+      else if (opt == 'k') kmer_length = std::stoi(optarg);
+      else if (opt == 't') threads_num = std::stoi(optarg);
+      else {
+        logging.WriteLog("Invalid option");
+        return false;
+      }
+    }
+    return true;
+  }
+
+  // src/Options.cpp:50-60: items = bases * error_rate * k (truncated), m = items * -ln(1e-6) / ln(2)^2 (truncated),
+  // H = ln(2) * m / items (truncated to uint8_t); all in double, in this order of operations
+  void EstimateBloomfilter(uint64_t all_bases, Logging& logging) {
+    if (filter_size != 0) return;
+    const double fpr = 1.0e-6;
+    const uint64_t item_number = all_bases * error_rate * kmer_length;
+    filter_size = (item_number * (-(std::log(fpr)))) / std::pow(std::log(2), 2);
+    num_hashes = (std::log(2) * filter_size) / item_number;
+    logging.WriteLog("all_bases : " + std::to_string(all_bases));
+    logging.WriteLog("item_number :" + std::to_string(item_number));
+    logging.WriteLog("get filter_size :" + std::to_string(filter_size));
+  }
+
+  void PrintParameters(Logging& logging) {
+    logging.WriteLog("readfile_name : " + readfile_name);
+    logging.WriteLog("filter_size : " + std::to_string(filter_size));
+    logging.WriteLog("num_hashes : " + std::to_string((int)num_hashes));
+    logging.WriteLog("kmer_length : " + std::to_string(kmer_length));
+    logging.WriteLog("error_rate : " + std::to_string(error_rate));
+  }
+};
+#endif  // PLATANUS3_SHIM_CORE_ONLY
+
+// ---- ReadFile: src/Load.cpp:6-127 ---------------------------------------------------------------------------------
+// The loader keeps the reference's observable behaviour: the key is the WHOLE header line
+// including '>' / '@'; a later record with the same header overwrites the sequence but its bases are still added to
+// all_bases; records shorter than k are dropped; FASTA sequence lines are concatenated; nothing strips '\r'; the
+// format is chosen by the first character of the file, not by the suffix; FASTQ is read strictly four lines at a
+// time without checking '@' / '+'.
 class ReadFile {
  public:
   ReadSet reads;
+  std::string file_name;
   uint32_t large_kmer_length = 25;  // Options::kmer_length default (src/Options.cpp:13)
+  std::string file_type;
+  Error error_code = 0;
   uint64_t all_bases = 0;
   KmerCount shortk_database;
+
+  ReadFile() {}
+  // src/Load.cpp:23-30: the last five characters of the name must be "fasta" or "fastq" (else error_code = 1);
+  // like std::string::substr there, a name shorter than five characters throws std::out_of_range
+  explicit ReadFile(Options& parameters) : file_name(parameters.readfile_name), large_kmer_length(parameters.kmer_length) {
+    if (file_name.size() < 5) throw std::out_of_range("ReadFile: file name shorter than its expected suffix");
+    file_type = file_name.substr(file_name.size() - 5);
+    if (file_type != "fasta" && file_type != "fastq") error_code = 1;
+  }
+
+  void LoadFile() {  // src/Load.cpp:32-49
+    std::string text;
+    if (!slurp(file_name, text) || text.empty()) return;
+    if (text[0] == '>') parse(text, &reads, false);
+    else if (text[0] == '@') parse(text, &reads, true);
+  }
+  void LoadFasta(ReadSet* loaded_reads, std::string name) {  // src/Load.cpp:51-76
+    std::string text;
+    if (slurp(name, text)) parse(text, loaded_reads, false);
+  }
+  void LoadFastq(ReadSet* loaded_reads, std::string name) {  // src/Load.cpp:78-103
+    std::string text;
+    if (slurp(name, text)) parse(text, loaded_reads, true);
+  }
+
+ private:
+  static bool slurp(const std::string& name, std::string& out) {
+    std::ifstream f(name, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    out.resize(n > 0 ? (size_t)n : 0);
+    if (n > 0) f.read(&out[0], n);
+    return true;
+  }
+  // One pass over the text.  A "header" is a line starting with '>' (FASTA) or every fourth line (FASTQ); other
+  // FASTA lines and the line after a FASTQ header extend the pending sequence.  A header commits the pending
+  // record -- and clears the pending sequence -- only if a non-empty header preceded it (src/Load.cpp:58-64,85-91);
+  // the end of the text commits whatever is pending, whatever its name (:72-75,:99-102).
+  void parse(const std::string& text, ReadSet* dst, bool fastq) {
+    std::string pending_name, pending_seq;
+    auto commit = [&]() {
+      if (pending_seq.size() >= large_kmer_length) {
+        (*dst)[pending_name] = pending_seq;
+        all_bases += pending_seq.size();
+      }
+    };
+    size_t pos = 0, line_no = 0;
+    while (pos < text.size()) {  // getline semantics: a final line without '\n' counts, a final '\n' adds no line
+      size_t eol = text.find('\n', pos);
+      if (eol == std::string::npos) eol = text.size();
+      const char first = eol > pos ? text[pos] : '\0';
+      const bool header = fastq ? (line_no % 4 == 0) : (first == '>');
+      if (header) {
+        if (!pending_name.empty()) {
+          commit();
+          pending_seq.clear();
+        }
+        pending_name.assign(text, pos, eol - pos);
+      } else if (!fastq || line_no % 4 == 1) {
+        pending_seq.append(text, pos, eol - pos);
+      }
+      pos = eol + 1;
+      line_no++;
+    }
+    commit();
+  }
+
+ public:
 
   // ReadFile::CountShortKmer (src/Load.cpp:105-127).  shortk_length is hard-wired to 21 in the reference
   // (bitset<42>, CompareBit(...,42)); any other value is rejected instead of silently miscounting.
@@ -362,5 +498,53 @@ class DeBruijnGraph {
     return b;
   }
 };
+
+// ---- Assemble<B> / Assemble_k: src/Assemble.cpp:6-54 ----------------------------------------------------------------
+#ifndef PLATANUS3_SHIM_CORE_ONLY
+template <typename LARGE_BITSET>
+int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
+  logging.WriteLog("Assemble");
+  input_reads.CountShortKmer(options.shortk_length);
+  logging.WriteLog("counted short kmer");
+  std::set<std::string> seedkmer;
+  BF<LARGE_BITSET> first_bloom_filter = MakeBF<LARGE_BITSET>(input_reads.reads, input_reads.shortk_database, options.filter_size,
+                                                            options.num_hashes, options.kmer_length, &seedkmer, logging);
+  logging.WriteLog("bloom filter loaded");
+  logging.WriteLog("get seed kmer");
+  logging.WriteLog("seed kmer num= " + std::to_string(seedkmer.size()));
+  DeBruijnGraph<LARGE_BITSET> first_dbg(options.kmer_length, first_bloom_filter, logging);
+  logging.WriteLog("start graph extention");
+  first_dbg.MakeDBG(seedkmer, options.filter_size, options.num_hashes, options.threads_num);
+  logging.WriteLog("de bruijn graph loaded");
+  first_dbg.CountNodeCoverage(input_reads.reads);
+  logging.WriteLog("count node coverage");
+  first_dbg.PrintGraph();
+  return 0;
+}
+
+// Every k the device path supports (21..64) is dispatched -- the reference's switch (src/Assemble.cpp:31-53) only
+// has 21, 25 and 63 in that range; like there, any other k returns 1 without doing anything.
+inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging) {
+  switch (options.kmer_length) {
+#define P3SHIM_CASE(K) \
+  case K:              \
+    return Assemble<std::bitset<2 * K>>(input_reads, options, logging);
+    P3SHIM_CASE(21) P3SHIM_CASE(22) P3SHIM_CASE(23) P3SHIM_CASE(24) P3SHIM_CASE(25) P3SHIM_CASE(26) P3SHIM_CASE(27)
+    P3SHIM_CASE(28) P3SHIM_CASE(29) P3SHIM_CASE(30) P3SHIM_CASE(31) P3SHIM_CASE(32) P3SHIM_CASE(33) P3SHIM_CASE(34)
+    P3SHIM_CASE(35) P3SHIM_CASE(36) P3SHIM_CASE(37) P3SHIM_CASE(38) P3SHIM_CASE(39) P3SHIM_CASE(40) P3SHIM_CASE(41)
+    P3SHIM_CASE(42) P3SHIM_CASE(43) P3SHIM_CASE(44) P3SHIM_CASE(45) P3SHIM_CASE(46) P3SHIM_CASE(47) P3SHIM_CASE(48)
+    P3SHIM_CASE(49) P3SHIM_CASE(50) P3SHIM_CASE(51) P3SHIM_CASE(52) P3SHIM_CASE(53) P3SHIM_CASE(54) P3SHIM_CASE(55)
+    P3SHIM_CASE(56) P3SHIM_CASE(57) P3SHIM_CASE(58) P3SHIM_CASE(59) P3SHIM_CASE(60) P3SHIM_CASE(61) P3SHIM_CASE(62)
+    P3SHIM_CASE(63) P3SHIM_CASE(64)
+#undef P3SHIM_CASE
+    default:
+      return 1;
+  }
+}
+
+inline void ShowUsage(void) {  // src/ShowInfo.cpp:9-12
+  std::cout << "Usage: platanus3 -i {readfile} -k {kmersize} -t {numthread}\n";
+}
+#endif  // PLATANUS3_SHIM_CORE_ONLY
 
 #endif  // PLATANUS3_SHIM_HPP
