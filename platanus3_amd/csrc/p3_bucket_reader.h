@@ -14,10 +14,12 @@
 // Calls f(recs, active_mask) with batches of 4*(16/sizeof(REC)) records of bucket pb (bit i of the mask says
 // whether recs[i] is a real record).  ALL threads of the workgroup must call this (it
 // synchronises).  valid: LDS byte array of P3_VALID_CAP entries; sc2: two LDS u32 scratch words.
-template <typename REC, u32 VCAP = P3_VALID_CAP, typename F>
+// TAGGED: the table byte also carries (segment index / tag_div) in its top 3 bits and f gets the tag of each of the
+// four vectors as a third argument (k_part_count: the source rank of a re-partitioned cell's segment group).
+template <typename REC, u32 VCAP = P3_VALID_CAP, bool TAGGED = false, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
                                                 const u32* __restrict__ ghist, u32 pb, uint8_t* valid, u32* sc2,
-                                                F f, u32 seg_begin = 0, u32 seg_count = P3_NWG) {
+                                                F f, u32 seg_begin = 0, u32 seg_count = P3_NWG, u32 tag_div = P3_NWG) {
   constexpr u32 RPV = 16 / sizeof(REC);  // records per 16-byte vector
   constexpr u32 VPC = 16 / RPV;          // vectors per 16-record chunk
   // segment descriptor of thread t < seg_count (segments [seg_begin, seg_begin+seg_count) of row pb)
@@ -45,7 +47,9 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       u32 hi = (my_c0 + my_nc) < (wb + wn) ? (my_c0 + my_nc) : (wb + wn);
       for (u32 c = lo; c < hi; c++) {
         const u32 left = my_n - ((c - my_c0) << 4);
-        valid[c - wb] = (uint8_t)(left < 16u ? left : 16u);
+        u32 e = left < 16u ? left : 16u;
+        if constexpr (TAGGED) e |= (threadIdx.x / tag_div) << 5;
+        valid[c - wb] = (uint8_t)e;
       }
     }
     __syncthreads();
@@ -59,7 +63,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
     // back to back; a vector is fetched only if its chunk holds a record at or beyond the vector's first slot
     // (gaps between estimated-capacity segments and segment tails cost no memory traffic): a lane with nothing
     // to fetch re-reads the window's first vector (one broadcast line) and its records stay masked out by `act`
-    auto fetch = [&](u32 jb, uint4 (&v)[4], u32 (&nval)[4]) {
+    auto fetch = [&](u32 jb, uint4 (&v)[4], u32 (&nval)[4]) {  // nval: table byte (count, and tag if TAGGED)
       const u32 j0 = jb + threadIdx.x;
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
@@ -70,7 +74,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       for (u32 u = 0; u < 4; u++) {
         const u32 j = j0 + u * B;
         if (j >= nvec) nval[u] = 0;
-        v[u] = vec[(nval[u] > (j % VPC) * RPV) ? j : 0u];
+        v[u] = vec[((nval[u] & 31u) > (j % VPC) * RPV) ? j : 0u];
       }
     };
     // software pipeline: the loads of batch i+1 are in flight while the consumer works on batch i
@@ -89,9 +93,11 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       if (jb + 4 * B < nvec) fetch(jb + 4 * B, vn, nvn);
       REC recs[4 * RPV];
       u32 act = 0;
+      u32 tags[4];
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
-        const u32 nvalid = nval[u];
+        const u32 nvalid = nval[u] & 31u;
+        tags[u] = nval[u] >> 5;
         const u32 first = ((j0 + u * B) % VPC) * RPV;
         if constexpr (sizeof(REC) == 4) {
           recs[4 * u + 0] = v[u].x;
@@ -109,7 +115,8 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
         for (u32 t = 0; t < RPV; t++)
           if (first + t < nvalid) act |= 1u << (u * RPV + t);
       }
-      f(recs, act);
+      if constexpr (TAGGED) f(recs, act, tags);
+      else f(recs, act);
     }
     __syncthreads();
   }

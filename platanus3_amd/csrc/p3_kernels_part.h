@@ -361,8 +361,13 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 144);
   const u64 tbase = (u64)sb * TS;  // this sub-bucket's window of tpairs (at most 7/8 TS entries are used)
   u32 cur_src = 0;
+  // A re-partitioned cell (xbits > 0) holds its 256 segments grouped by source rank; with at most 8 sources the
+  // whole cell is read in ONE sweep and every record learns its source from the segment tag.  A queued record
+  // keeps the tag in the top xbits bits of its low word (they hold the cell's constant xval otherwise).
+  const bool tagged = POS && xbits > 0 && n_src > 1 && n_src <= 8;
   auto slow_insert = [&](REC item) {
     const u32 rem = (u32)item & rem_mask;
+    const u32 item_src = tagged ? ((u32)item >> (32 - xbits)) : cur_src;
     u32 slot = (rem * 0x9E3779B1u) >> (32 - ts_log2);
     // double hashing (odd step, power-of-two table): no primary clustering, so the longest chain among the 64
     // lanes of a drain round -- which is what the round costs -- stays short
@@ -378,7 +383,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           // first instance of a key: (source | slot | position) appended in insertion order -- dense 8-byte
           // stores (a per-slot array cost a 64-byte line per 4-byte write: 0.9 GB of write-back per launch)
           if constexpr (POS)
-            tpairs[tbase + ticket] = ((u64)cur_src << 56) | ((u64)slot << 32) | (u32)((u64)item >> 32);
+            tpairs[tbase + ticket] = ((u64)item_src << 56) | ((u64)slot << 32) | (u32)((u64)item >> 32);
         }
       }
       if (old == P3_EMPTY32 || old == rem) {
@@ -396,43 +401,64 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   REC* wq = reinterpret_cast<REC*>(valid + VCAP) + (threadIdx.x >> 6) * QCAP;
   u32 qn = 0;  // wave-uniform
   const unsigned long long lt_mask = (1ULL << lane) - 1;
-  for (u32 src = 0; src < n_src; src++) {
-    cur_src = src;
-    const u32 row = xbits ? pb_local : src * rows + pb_local;
-    const REC* part_src = xbits ? part : part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
-    const u32 segs = xbits ? P3_NWG / n_src : P3_NWG;
-    bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8, [&](REC (&r)[NBATCH], u32 act) {
+  constexpr int RPVEC = 16 / (int)sizeof(REC);  // records per 16-byte vector of the reader
+  const u32 xtop_shift = xbits ? 32 - xbits : 0;
+  auto consume = [&](REC (&r)[NBATCH], u32 act, const u32* tg) {
 #pragma unroll
-      for (int g0 = 0; g0 < NBATCH; g0 += G) {
-        u32 rem[G], slot[G], cur[G];
+    for (int g0 = 0; g0 < NBATCH; g0 += G) {
+      u32 rem[G], slot[G], cur[G];
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-          rem[t] = (u32)r[g0 + t] & rem_mask;
-          slot[t] = (rem[t] * 0x9E3779B1u) >> (32 - ts_log2);
-          cur[t] = tkey[slot[t]];
-        }
-#pragma unroll
-        for (int t = 0; t < G; t++) {
-          const int i = g0 + t;
-          const bool mine = (act & (1u << i)) && ((((u32)r[i] >> rem_bits) & sub_mask) == subsel);
-          const bool hit = mine && cur[t] == rem[t];
-          if (hit) atomicAdd(&tcnt[slot[t]], weight_of(r[i]));
-          const bool miss = mine && !hit;
-          const unsigned long long bal = __ballot(miss);
-          if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = r[i];
-          qn += (u32)__popcll(bal);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        while (qn >= 64) {
-          qn -= 64;
-          slow_insert(wq[qn + lane]);
-        }
+      for (int t = 0; t < G; t++) {
+        rem[t] = (u32)r[g0 + t] & rem_mask;
+        slot[t] = (rem[t] * 0x9E3779B1u) >> (32 - ts_log2);
+        cur[t] = tkey[slot[t]];
       }
-    }, xbits ? src * segs : 0u, segs);
-    // the queue is emptied before the next source so that a first insertion is credited to the right rank
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane < qn) slow_insert(wq[lane]);
-    qn = 0;
+#pragma unroll
+      for (int t = 0; t < G; t++) {
+        const int i = g0 + t;
+        const bool mine = (act & (1u << i)) && ((((u32)r[i] >> rem_bits) & sub_mask) == subsel);
+        const bool hit = mine && cur[t] == rem[t];
+        if (hit) atomicAdd(&tcnt[slot[t]], weight_of(r[i]));
+        const bool miss = mine && !hit;
+        const unsigned long long bal = __ballot(miss);
+        if (miss) {
+          REC q = r[i];
+          if constexpr (POS) {
+            if (tg) q = (q & ~((u64)(0xffffffffu << xtop_shift) & 0xffffffffULL)) | ((u64)tg[i / RPVEC] << xtop_shift);
+          }
+          wq[qn + (u32)__popcll(bal & lt_mask)] = q;
+        }
+        qn += (u32)__popcll(bal);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (qn >= 64) {
+        qn -= 64;
+        slow_insert(wq[qn + lane]);
+      }
+    }
+  };
+  if (tagged) {
+    if constexpr (POS) {
+      bucket_for_each<REC, VCAP, true>(part, seg_off, ghist, pb_local, valid, sc + 8,
+                                       [&](REC (&r)[NBATCH], u32 act, u32 (&tg)[4]) { consume(r, act, tg); }, 0u, P3_NWG,
+                                       P3_NWG / n_src);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane < qn) slow_insert(wq[lane]);
+      qn = 0;
+    }
+  } else {
+    for (u32 src = 0; src < n_src; src++) {
+      cur_src = src;
+      const u32 row = xbits ? pb_local : src * rows + pb_local;
+      const REC* part_src = xbits ? part : part + roff[src] - seg_off[(u64)src * rows * P3_NWG];
+      const u32 segs = xbits ? P3_NWG / n_src : P3_NWG;
+      bucket_for_each<REC, VCAP>(part_src, seg_off, ghist, row, valid, sc + 8,
+                                 [&](REC (&r)[NBATCH], u32 act) { consume(r, act, nullptr); }, xbits ? src * segs : 0u, segs);
+      // the queue is emptied before the next source so that a first insertion is credited to the right rank
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (lane < qn) slow_insert(wq[lane]);
+      qn = 0;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {

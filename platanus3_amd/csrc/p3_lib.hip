@@ -730,7 +730,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (use_dedup) {
     const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
-    const bool est = est_mode(c);
+    // the k-mer and probe partitions are rank-local (nothing of them is exchanged), so the estimated-capacity
+    // form serves the multi-rank protocol as well
+    const bool est = c->est_ok && c->sizing_opt != 1;
     double mean_k = (double)wg_window_bound(c) / P3_NB;
     if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * P3_NWG);
     if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * P3_NWG);
@@ -1566,10 +1568,12 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
                 (unsigned long long)c->cstats.max_count);
   HIPCHK(c, hipSetDevice(c->device));
   rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
-  if (rc == P3_ERETRY_INTERNAL && !c->protocol) {
+  if (rc == P3_ERETRY_INTERNAL) {
     // an estimated-capacity partition overflowed: repeat with exact offsets (the count stage too if its
-    // solid-window partition was the one that overflowed)
+    // solid-window partition was the one that overflowed; never the case under the multi-rank protocol, whose
+    // count-stage partitions are exact)
     if (!c->counted) {
+      if (c->protocol) return fail(c, P3_EHIP, "internal retry failed");
       rc = do_count(c);
       if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);
       if (rc) return rc == P3_ERETRY_INTERNAL ? fail(c, P3_EHIP, "internal retry failed") : rc;

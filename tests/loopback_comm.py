@@ -3,15 +3,33 @@ same GPU) and exchange through these barrier-synchronised copies.  It lets the r
 (p3_mr_* with n_ranks = 2, 4, 8) be exercised on a one-GPU box; the torch.distributed form of the same calls is
 covered by the gloo tests."""
 import threading
+import time
 
 import torch
 
 
 class LoopbackWorld:
-    def __init__(self, n):
+    def __init__(self, n, serialize=False):
         self.n = n
         self.barrier = threading.Barrier(n)
         self.slot = [None] * n
+        # serialize=True: only one rank computes at a time (a rank holds the token between collectives), so per-rank
+        # kernel timings are not inflated by the other ranks sharing the GPU (tools/exp_loopback_scale.py)
+        self.token = threading.Lock() if serialize else None
+        self.held = [0.0] * n   # seconds each rank spent between collectives (compute + host overhead)
+        self._t0 = [0.0] * n
+
+    def begin(self, rank=None):
+        if self.token is not None:
+            self.token.acquire()
+        if rank is not None:
+            self._t0[rank] = time.perf_counter()
+
+    def end(self, rank=None):
+        if rank is not None:
+            self.held[rank] += time.perf_counter() - self._t0[rank]
+        if self.token is not None:
+            self.token.release()
 
     def comm(self, rank):
         return LoopbackComm(self, rank)
@@ -22,6 +40,9 @@ class LoopbackComm:
         self.w, self.rank, self.world = world, rank, world.n
 
     def _exchange(self, item):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.w.end(self.rank)
         self.w.slot[self.rank] = item
         self.w.barrier.wait()
         items = list(self.w.slot)
@@ -31,6 +52,7 @@ class LoopbackComm:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         self.w.barrier.wait()
+        self.w.begin(self.rank)
 
     def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
         n = self.world
@@ -62,10 +84,12 @@ class LoopbackComm:
         items = self._exchange(int(v))
         r = max(items)
         self.w.barrier.wait()
+        self.w.begin(self.rank)
         return r
 
     def all_reduce_sum(self, v):
         items = self._exchange(int(v))
         r = sum(items)
         self.w.barrier.wait()
+        self.w.begin(self.rank)
         return r
