@@ -305,3 +305,77 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
     for r in results:
         assert np.array_equal(r[2], ebloom)
     assert sorted(set(s for r in results for s in r[3])) == eseeds
+
+
+def test_beyond_2g_bases_uses_direct_kernels_and_keeps_the_invariants():
+    """Maximum sizes: 2.16 G bases (> 2^31, so 33-bit base positions) exceed what the partitioned kernels index and
+    go through the direct global-table kernels.  The input is X||X (the same 7.2 M reads twice), so -- without an
+    oracle that large -- the result is pinned by what X alone gives through the partitioned path: the same key set
+    with every count doubled; hence every window passes the gate, the seeds are exactly the distinct first k-mers,
+    and the Bloom vector has no false negatives."""
+    R, k = 7_200_000, 31
+    b, o = synth.reads(seed=9, total_reads=R, read_len=150)
+    c = capi.Context(0)
+    c.load_reads(b, o, k)
+    c.count_short()
+    assert c.get_info("count_mode") == 2
+    keys, counts = c.export_counts()
+    c.close()
+    bb = np.concatenate([b, b])
+    oo = np.concatenate([o, o[1:] + o[-1]])
+    assert bb.size > (1 << 31)
+    from bench import bloom_sizing
+    m, H = bloom_sizing(int(bb.size), k)
+    c = capi.Context(0)
+    c.load_reads(bb, oo, k)
+    st = c.count_short()
+    assert c.get_info("count_mode") == 1
+    assert st["n_windows"] == 2 * R * 130 and st["n_solid"] == st["n_distinct"] == keys.size
+    k2, c2 = c.export_counts()
+    assert np.array_equal(keys, k2) and np.array_equal(counts * np.uint64(2), c2)
+    c.make_bloom(k, m, H)
+    bs = c.bloom_stats()
+    assert bs["n_passing"] == bs["n_windows_k"] == 2 * R * 120 and bs["n_seed_reads"] == 2 * R
+    seeds = c.export_seeds()
+    lut = np.zeros(256, np.uint64)
+    lut[ord("C")], lut[ord("G")], lut[ord("T")] = 1, 2, 3
+    starts = o[:-1].astype(np.int64)
+    first = np.zeros(R, np.uint64)
+    for i in range(k):
+        first = (first << np.uint64(2)) | lut[b[starts + i]]
+    assert np.array_equal(np.unique(first), seeds[:, 0])
+    samp = first[::97]
+    rc = np.zeros_like(samp)
+    for i in range(k):
+        rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
+    assert c.bloom_query(np.minimum(samp, rc)).all()
+    c.close()
+
+
+@pytest.mark.parametrize("R,L,k,ppm", [(2_000_000, 150, 31, 5000), (4000, 10_000, 63, 10_000), (300_000, 150, 21, 5000),
+                                       (300_000, 150, 41, 5000), (300_000, 150, 51, 5000), (300_000, 150, 61, 5000)])
+def test_baseline_shapes_partitioned_equals_direct(R, L, k, ppm):
+    """BASELINE.json's other configurations, scaled to seconds (#3's per-GPU shard shape, #4's long reads at k=63 with
+    2-word keys, #5's k sweep): the partitioned/dedup path and the direct global-table path are two independent
+    device implementations of the same stage and must export identical tables, Bloom words and seeds."""
+    import hashlib
+    from bench import bloom_sizing
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    b, o = synth.reads(seed=3, total_reads=R, read_len=L, sub_rate_ppm=ppm)
+    m, H = bloom_sizing(int(b.size), k)
+    res = []
+    for direct in (False, True):
+        c = capi.Context(0)
+        if direct:
+            c.set_option("count_mode", 1)
+            c.set_option("bloom_mode", 1)
+        c.load_reads(b, o, k)
+        c.run_pass(k, m, H)
+        assert c.get_info("count_mode") == (1 if direct else 2)
+        keys, counts = c.export_counts()
+        res.append((sha(keys), sha(counts), sha(c.export_bloom()), sha(c.export_seeds()), c.bloom_stats()))
+        assert int(counts.sum()) == R * (L - 20)
+        c.close()
+    assert res[0] == res[1]
