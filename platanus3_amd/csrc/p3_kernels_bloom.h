@@ -35,10 +35,19 @@ struct Stg {
   static constexpr u32 CAP = 2 * CHUNK;           // one 128-byte LDS row per bucket
 };
 
-// bucket / slot hash of a k-mer key (ours, not part of the reference)
+// Bucket / slot hashes of a k-mer key (ours, not part of the reference).  Everything derives from ONE 32-bit fold
+// of the key: bucket and sub-bucket = top bits of fold * C1, LDS slot = top bits of fold * C2, probe step from
+// fold * C3 -- three 32-bit multiplies in all (v_mul_lo_u32 is quarter rate; a 64-bit finaliser costs twelve).
+// Keys with equal folds merely share a probe chain; the sets compare full keys.
 template <int NW>
-__device__ __forceinline__ u64 khash(u64 lo, u64 hi) {
-  return NW == 1 ? mix64(lo ^ 0x9E3779B97F4A7C15ULL) : mix64(lo ^ mix64(hi ^ 0x9E3779B97F4A7C15ULL));
+__device__ __forceinline__ u32 kfold(u64 lo, u64 hi) {
+  u32 x = (u32)lo ^ ((u32)(lo >> 32) * 0x85EBCA6Bu);
+  if (NW == 2) x ^= ((u32)hi * 0xC2B2AE3Du) ^ ((u32)(hi >> 32) * 0x27D4EB2Fu);
+  return x ^ (x >> 15);
+}
+template <int NW>
+__device__ __forceinline__ u64 khash(u64 lo, u64 hi) {  // bits 63..54 = bucket, the next bits = sub-bucket
+  return (u64)(kfold<NW>(lo, hi) * 0x9E3779B1u) << 32;
 }
 
 // Segment sizing.  Exact mode (segcap == 0): a histogram pass + scan gave every (bucket, workgroup) segment its
@@ -456,24 +465,15 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
   const u32 limit = TS - (TS >> 3);
   (void)CHUNK;
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
-  // slot / sub-bucket hash: the full 64-bit mix only when a sub-bucket split needs the scatter's bucket bits
-  auto fold32 = [&](u64 lo, u64 hi) -> u32 {
-    u32 x = (u32)lo ^ (u32)(lo >> 32);
-    if (NW == 2) x ^= (u32)hi * 0x85EBCA6Bu ^ (u32)(hi >> 32);
-    return x;
-  };
   auto slot_of = [&](u64 lo, u64 hi, bool& mine) -> u32 {
+    const u32 f = kfold<NW>(lo, hi);
     mine = true;
-    if (sbits) {
-      const u64 h = khash<NW>(lo, hi);
-      mine = ((u32)(h >> (64 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
-      return (u32)(h >> 16) & (TS - 1);
-    }
-    return (fold32(lo, hi) * 0x9E3779B1u) >> (32 - ts_log2);
+    if (sbits) mine = (((f * 0x9E3779B1u) >> (32 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
+    return (f * 0x2C1B3C6Du) >> (32 - ts_log2);
   };
   auto slow_insert = [&](u64 lo, u64 hi, u32 slot) {
     // double hashing (odd step): short probe chains -> short drain rounds (see k_part_count)
-    const u32 step = ((fold32(lo, hi) * 0xC2B2AE35u) >> 15) | 1u;
+    const u32 step = ((kfold<NW>(lo, hi) * 0xC2B2AE35u) >> 15) | 1u;
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
       if constexpr (NW == 1) {

@@ -44,7 +44,16 @@ __host__ __device__ constexpr u64 p3_modinv64(u64 a) {
 
 __host__ __device__ __forceinline__ u64 mix42(u64 x) {
   x ^= x >> 21;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // x < 2^42 and C < 2^41: low 42 bits of the product = xl*cl (one 32x32->64 multiply) plus the low 10 bits of
+  // the two cross terms, which 24-bit multiplies (full rate) give exactly
+  const u32 xl = (u32)x, xh = (u32)(x >> 32);
+  const u64 p = (u64)xl * (u32)P3_MIX_C;
+  const u32 cross = __umul24(xl, (u32)(P3_MIX_C >> 32)) + __umul24(xh, (u32)P3_MIX_C & 0xffffffu);
+  return (p + ((u64)cross << 32)) & P3_MASK42;
+#else
   return (x * P3_MIX_C) & P3_MASK42;
+#endif
 }
 __host__ __device__ __forceinline__ u64 unmix42(u64 g) {
   u64 x = (g * P3_MIX_CINV) & P3_MASK42;
