@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-reads", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-protocol", action="store_true",
                     help="run the multi-rank protocol code path even with one rank (testing)")
