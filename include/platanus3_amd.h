@@ -80,7 +80,7 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
  *                 both forms record by record, so ranks need not agree.
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
- * "rs_log2", "distinct_kmers", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
+ * "rs_log2", "distinct_kmers", "est_fallbacks", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 

@@ -90,6 +90,7 @@ struct p3_ctx {
   bool agg = false;          // this rank's send partition is pre-aggregated (apart)
   DevBuf apart;
   u64 agg_padded = 0, agg_distinct_est = 0;
+  u64 est_fallbacks = 0;  // times an estimated-capacity partition overflowed and the stage was repeated exactly
   u32 xbits = 0;
   DevBuf lpart;
   // coverage gate: 1 = probe the solid-key regions per window, 2 = return path (non-solid positions come back
@@ -491,6 +492,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     c->est_ok = false;
+    c->est_fallbacks++;
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
   *overflowed = h[3] != 0;
@@ -852,6 +854,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     c->est_ok = false;
+    c->est_fallbacks++;
     c->counted = c->counted && !hall[26];
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
@@ -1125,6 +1128,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
+  else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);

@@ -379,3 +379,72 @@ def test_baseline_shapes_partitioned_equals_direct(R, L, k, ppm):
         assert int(counts.sum()) == R * (L - 20)
         c.close()
     assert res[0] == res[1]
+
+
+@pytest.mark.parametrize("k", [31, 45])
+def test_skewed_keys_overflow_estimated_segments_and_retry_exactly(oracle, k):
+    """Estimated-capacity partitions assume hash-spread keys.  Half of these reads are low-complexity repeats
+    (poly-A, (AC)n, (ACG)n, (ACGT)n ...): a handful of 21-mers / k-mers with tens of thousands of instances each, all
+    landing in the same few segments, which must overflow the estimate, raise the flag and repeat the stage with
+    exact offsets -- with the same results as the oracle, and as a run that was exact from the start."""
+    rng = np.random.default_rng(7)
+    b0, o0 = synth.reads(seed=17, total_reads=12000, read_len=150)
+    units = [b"A", b"AC", b"ACG", b"ACGT", b"AAC", b"AGGT", b"T", b"CCG"]
+    reps = []
+    for i in range(12000):
+        u = units[i % len(units)]
+        s = (u * (150 // len(u) + 2))[rng.integers(0, len(u)):][:150]
+        reps.append(np.frombuffer(s, dtype=np.uint8))
+    reads = [b0[int(o0[i]):int(o0[i + 1])] for i in range(12000)] + reps
+    order = rng.permutation(len(reads))
+    b = np.concatenate([reads[i] for i in order])
+    o = np.concatenate([[0], np.cumsum([reads[i].size for i in order])]).astype(np.uint64)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    run_and_compare(c, oracle, (b, o), k, m, H)          # default sizing: estimated first
+    assert c.get_info("count_mode") == 2 and c.get_info("bloom_mode") == 3
+    assert c.get_info("est_fallbacks") >= 1               # ... and at least one stage had to fall back
+    keys, counts = c.export_counts()
+    words = c.export_bloom()
+    c.close()
+    c = capi.Context(0)
+    c.set_option("part_sizing", 1)                         # exact from the start
+    c.load_reads(b, o, k)
+    c.run_pass(k, m, H)
+    assert c.get_info("est_fallbacks") == 0
+    k2, c2 = c.export_counts()
+    assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+    c.close()
+
+
+def test_speculative_pass_survives_stale_hints(oracle):
+    """p3_run_pass re-uses what the previous pass learnt (table splits, passing-window count, non-solid count) and
+    checks only at its single synchronisation point whether that still held.  One context is driven through changes
+    of k, of the Bloom size and of the reads (larger, tiny, skewed); every pass must still equal the oracle."""
+    def check(c, b, o, k, m, H):
+        keys, counts = c.export_counts()
+        ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+        ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+        assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+        assert np.array_equal(c.export_bloom(), ebloom)
+        c.k = k
+        assert seeds_as_strings(c) == eseeds
+
+    c = capi.Context(0)
+    a = synth.reads(seed=21, total_reads=8000, read_len=150)
+    big = synth.reads(seed=22, total_reads=40000, read_len=150)
+    tiny = synth.reads(seed=23, total_reads=40, read_len=150)
+    rep = np.frombuffer((b"ACGGT" * 40)[:150] * 3000, dtype=np.uint8)
+    skew = (np.concatenate([a[0], rep]), np.concatenate([a[1], a[1][-1] + np.arange(1, 3001, dtype=np.uint64) * np.uint64(150)]))
+    plan = [(a, 31, 0), (a, 31, 0), (a, 21, 0), (a, 31, 1 << 22), (big, 31, 0), (big, 31, 0), (big, 47, 0), (tiny, 31, 0),
+            (skew, 31, 0), (skew, 31, 0), (a, 63, 0), (a, 31, 0)]
+    loaded = None
+    for reads, k, m_in in plan:
+        b, o = reads
+        if loaded is not reads or c.min_len != k:
+            c.load_reads(b, o, min_len=k)
+            loaded, c.min_len = reads, k
+        m, H = oracle.estimate_bloom(int(b.size), k) if m_in == 0 else (m_in, 10)
+        c.run_pass(k, m, H)
+        check(c, b, o, k, m, H)
+    c.close()
