@@ -88,6 +88,10 @@ __device__ __forceinline__ u64 std_hash_key(u64 lo, u64 hi, u32 k) {
   return h;
 }
 
+// wave64 ballot on a bool: the HIP ballot64(int) wrapper round-trips the predicate through an integer and costs a
+// v_cndmask + v_cmp per call; this is the lane mask itself
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
 
 __device__ __forceinline__ u64 fmix64(u64 v) {

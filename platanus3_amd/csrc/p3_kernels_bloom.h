@@ -112,7 +112,7 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
   u32 n0 = s.cnt[t] & 0x7fffffffu;
   n0 = n0 < CAP ? n0 : CAP;
   const bool ready = final_flush ? (n0 != 0) : (n0 >= CHUNK);
-  const u64 mask = __ballot(ready);
+  const u64 mask = ballot64(ready);
   const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
   unsigned short* wl = s.list + (t & ~63u);
   if (ready) wl[rank] = (unsigned short)t;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void stage_round(const StageLds& s, REC* __restrict__
     }
     // workgroup-wide OR of "pend != 0" with the round's two barriers only: the flag word is written before the
     // first, read between the two and cleared (by thread 0) after the second; the next round uses the other word
-    if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+    if (ballot64(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
     __syncthreads();
     stage_flush<REC>(s, out, false, est);
     more = (int)s.flag[c.par];
@@ -229,7 +229,7 @@ __device__ __forceinline__ void stage_run(const StageLds& s, REC* __restrict__ o
         pend &= ~(1u << i);
       }
     }
-    if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+    if (ballot64(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
     __syncthreads();
     REC rec2[N];
     u32 bkt2[N];
@@ -244,7 +244,7 @@ __device__ __forceinline__ void stage_run(const StageLds& s, REC* __restrict__ o
 #pragma unroll
       for (int i = 0; i < N; i++)
         if ((pend & (1u << i)) && stage_put<REC>(s, bkt[i], rec[i])) pend &= ~(1u << i);
-      if (__ballot(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
+      if (ballot64(pend != 0) && (threadIdx.x & 63) == 0) s.flag[c.par] = 1;
       __syncthreads();
       stage_flush<REC>(s, out, false, est);
       more = (int)s.flag[c.par];
@@ -578,7 +578,7 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
         const bool want = mine[t] && (act & (1u << (g0 + t)));
         const bool hit = want && st[t] == 2u && cur_lo[t] == lo[t] && cur_hi[t] == hi[t];
         const bool miss = want && !hit;
-        const unsigned long long bal = __ballot(miss);
+        const unsigned long long bal = ballot64(miss);
         if (miss) wq[qn + (u32)__popcll(bal & lt_mask)] = r[g0 + t];
         qn += (u32)__popcll(bal);
       }
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
   for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
     const u32 i = i0 + threadIdx.x;
     const bool full = (i < TS) && ((NW == 1) ? (tlo[i] != ~0ULL) : (tstate[i] == 2u));
-    const unsigned long long bal = __ballot(full);
+    const unsigned long long bal = ballot64(full);
     u32 wbase = 0;
     if (lane == 0 && bal) wbase = atomicAdd(&sc[1], (u32)__popcll(bal));
     wbase = __shfl(wbase, 0, 64);

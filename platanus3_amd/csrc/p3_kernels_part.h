@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         const bool hit = mine && cur[t] == rem[t];
         if (hit) atomicAdd(&tcnt[slot[t]], weight_of(r[i]));
         const bool miss = mine && !hit;
-        const unsigned long long bal = __ballot(miss);
+        const unsigned long long bal = ballot64(miss);
         if (miss) {
           REC q = r[i];
           if constexpr (POS) {
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     const u32 i = i0 + threadIdx.x;
     const u32 rem = (i < TS) ? tkey[i] : P3_EMPTY32;
     const bool full = rem != P3_EMPTY32;
-    const unsigned long long bal = __ballot(full);
+    const unsigned long long bal = ballot64(full);
     u32 wbase = 0;
     if (lane == 0 && bal) wbase = atomicAdd(&s_cur, (u32)__popcll(bal));
     wbase = __shfl(wbase, 0, 64);
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
           pr = tpairs[tbase + t];
           one = tcnt[(u32)(pr >> 32) & (TS - 1)] == 1;
         }
-        const unsigned long long bal = __ballot(one);
+        const unsigned long long bal = ballot64(one);
         u32 wbase = 0;
         if (lane == 0 && bal) wbase = atomicAdd(&s_sing[0], (u32)__popcll(bal));
         wbase = __shfl(wbase, 0, 64);

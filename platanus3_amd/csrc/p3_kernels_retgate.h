@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* _
         const u32 xv = (u32)r[i] >> (32 - xbits);
         for (u32 x = 0; x < ncell; x++) {  // wave-uniform loop over the few target cells
           const bool mine = on && xv == x;
-          const unsigned long long bal = __ballot(mine);
+          const unsigned long long bal = ballot64(mine);
           if (bal == 0) continue;
           u32 base = 0;
           if (lane == (u32)__ffsll((long long)bal) - 1) base = atomicAdd(&cur[(row_local << xbits) | x], (u32)__popcll(bal));
