@@ -74,6 +74,10 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "bloom_slices" 1 (default) = after dedup, probe positions are partitioned by bit-vector slice and OR-ed
  *                 in LDS (bloom_mode reads back 3); 0 = global atomicOr per probe (bloom_mode 2)
  *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 14; 2-word keys use 2 less)
+ *   "count_split" 0 = auto: when a level-1 bucket would need an 8-way or finer sub-bucket split (large inputs, > ~3 M
+ *                 reads of 150 bp), the position records are partitioned a second time (k_split) into 1024 cells per
+ *                 group of 1024 >> x buckets and the groups are counted one after the other, each cell read once;
+ *                 1 = never; x+1 (2..6) = force x split bits (tests).  p3_get_info "split_xbits" reads back x.
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 3x -- fewer bytes to

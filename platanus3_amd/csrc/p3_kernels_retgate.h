@@ -261,12 +261,21 @@ __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 
 
 // ---- sender-side pre-aggregation (multi-rank): k_part_count in P3_K2_AGG_OUT mode leaves one record per distinct
 // local key in its sub-bucket's window of the pair buffer; these two kernels turn that into a partition in the
-// standard format (segment j < 2^sbits of bucket b = sub-bucket j; the other segments are empty).
+// standard format (256 segments per bucket).
+// A sub-bucket's n records are laid out over per = 256 >> sbits consecutive segments in slices of
+// ceil(n / per) rounded up to 16 records (so only the last slice is padded): downstream kernels that share work by
+// segment index (k_split, k_repart_*) then see a balanced partition, as from the level-1 scatter.
+__device__ __forceinline__ u32 agg_slice(u32 n, u32 per) { return (((n + per - 1) / per) + 15u) & ~15u; }
+
 __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P3_NB * P3_NWG) return;
   const u32 pb = i / P3_NWG, j = i % P3_NWG;
-  ghist[i] = j < (1u << sbits) ? sb_info[(pb << sbits) + j].y : 0u;
+  const u32 per = P3_NWG >> sbits, sub = j / per, sl = j % per;
+  const u32 n = sb_info[(pb << sbits) + sub].y;
+  const u32 slice = agg_slice(n, per);
+  const u32 done = sl * slice;
+  ghist[i] = done >= n ? 0u : (n - done < slice ? n - done : slice);
 }
 
 __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
@@ -275,8 +284,100 @@ __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pai
   const u32 sb = blockIdx.x;
   const u32 pb = sb >> sbits, sub = sb & ((1u << sbits) - 1);
   const u32 n = sb_info[sb].y;
+  const u32 per = P3_NWG >> sbits;
+  const u32 slice = agg_slice(n, per);
   const u64* src = pairs + ((u64)sb << ts_log2);
-  u64* dst = out + seg_off[pb * P3_NWG + sub];
-  for (u32 t = threadIdx.x; t < n; t += blockDim.x) dst[t] = src[t];
+  const u32* so = seg_off + pb * P3_NWG + sub * per;
+  for (u32 t = threadIdx.x; t < n; t += blockDim.x) out[so[t / slice] + (t % slice)] = src[t];
 }
 
+// ---- k_split: second-level partition of position records ----------------------------------------------------------
+// When a bucket holds more distinct keys than an LDS table takes, reading it 2^s times (one sub-bucket per
+// workgroup) multiplies the count kernel's work by 2^s.  Instead `rows` consecutive level-1 buckets are split once
+// more by the next xbits bits of g into rows << xbits (<= 1024) CELLS, through the same LDS stager as the level-1
+// scatter.  To keep all 1024 stager rows busy a workgroup reads from 1024 >> xbits input segments at once: every group
+// of 2^xbits lanes walks its own list of (bucket, segment) items, two 16-byte vectors per lane and step.  Workgroup w takes, from
+// every bucket of source w / (256 / n_src), the n_src segments congruent to w modulo 256 / n_src -- so segment w of
+// every cell is single-source (the count kernel's source tags rely on that) and the work is balanced.
+// Output: standard [cell][256] segments of estimated capacity (est.segcap, counts to est.ghist_out, *est.ovf on
+// overflow).  in_segoff / in_ghist: [n_src][desc_rows][256] descriptors; the rows used are first_row .. first_row+rows.
+__global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict__ in, const u32* __restrict__ in_segoff,
+                                                          const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
+                                                          u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
+                                                          u64* __restrict__ out, EstSeg est) {
+  extern __shared__ __align__(16) u32 lds[];
+  const StageLds stg = stage_layout(lds);
+  u32* item_off = lds + P3_STAGE_WORDS;  // [rows * n_src] first record of the item (relative to the source's data)
+  u32* item_cnt = item_off + P3_NB;      // [rows * n_src] records
+  u32* s_maxsteps = item_cnt + P3_NB;
+  stage_init(stg, nullptr, est);
+  const u32 wps = P3_NWG / n_src;  // workgroups per source
+  const u32 src = blockIdx.x / wps, j0 = blockIdx.x % wps;
+  const u32 n_items = rows * n_src;  // <= 1024
+  for (u32 i = threadIdx.x; i < n_items; i += blockDim.x) {
+    const u32 r = i / n_src, t = i % n_src;
+    const u64 d = ((u64)src * desc_rows + first_row + r) * P3_NWG + j0 + t * wps;
+    item_off[i] = in_segoff[d];
+    item_cnt[i] = in_ghist[d];
+  }
+  if (threadIdx.x == 0) *s_maxsteps = 0;
+  __syncthreads();
+  const u64* data = in + roff[src] - in_segoff[(u64)src * desc_rows * P3_NWG];
+  // 2^xbits lanes per group: (1024 >> xbits) groups x 2^xbits cells each = all 1024 stager rows in play per round
+  const u32 GL = 1u << xbits, ngroups = P3_PART_THREADS >> xbits;
+  const u32 grp = threadIdx.x >> xbits, gl = threadIdx.x & (GL - 1);
+  // steps (of 2 GL vectors: two per lane) this group needs for its items grp, grp + ngroups, ...
+  u32 my_steps = 0;
+  for (u32 i = grp; i < n_items; i += ngroups) my_steps += ((item_cnt[i] + 1) / 2 + 2 * GL - 1) / (2 * GL);
+  if (gl == 0) atomicMax(s_maxsteps, my_steps);
+  __syncthreads();
+  const u32 max_steps = *s_maxsteps;
+  StageCarry<u64> carry;
+  carry.has = false;
+  carry.par = 0;
+  carry.bkt = 0;
+  carry.rec = 0;
+  u32 it = grp, vi = 0;  // current item and first vector of the next step
+  u32 cnt = it < n_items ? item_cnt[it] : 0, off = it < n_items ? item_off[it] : 0;
+  for (u32 step = 0; step < max_steps; step++) {
+    while (it < n_items && vi * 2 >= cnt) {  // item exhausted (or empty): next one of this group
+      it += ngroups;
+      vi = 0;
+      if (it < n_items) {
+        cnt = item_cnt[it];
+        off = item_off[it];
+      }
+    }
+    u64 rec[4];
+    u32 bkt[4];
+    u32 pend = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      rec[t] = 0;
+      bkt[t] = 0;
+    }
+    if (it < n_items) {
+      const uint4* vecs = reinterpret_cast<const uint4*>(data + off);
+      const u32 rbase = (it / n_src) << xbits;
+      uint4 q[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const u32 v = vi + gl + GL * h;
+        q[h] = vecs[v * 2 < cnt ? v : 0u];  // branch-free: a lane past the end re-reads vector 0 and masks it out
+      }
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const u32 v = vi + gl + GL * h;
+        rec[2 * h] = ((u64)q[h].y << 32) | q[h].x;
+        rec[2 * h + 1] = ((u64)q[h].w << 32) | q[h].z;
+        bkt[2 * h] = rbase | (q[h].x >> (32 - xbits));
+        bkt[2 * h + 1] = rbase | (q[h].z >> (32 - xbits));
+        if (v * 2 < cnt) pend |= 1u << (2 * h);
+        if (v * 2 + 1 < cnt) pend |= 2u << (2 * h);
+      }
+      vi += 2 * GL;
+    }
+    stage_round<u64, 4>(stg, out, est, rec, bkt, pend, carry);
+  }
+  stage_finish<u64>(stg, out, est, carry);
+}

@@ -90,6 +90,11 @@ struct p3_ctx {
   bool agg = false;          // this rank's send partition is pre-aggregated (apart)
   DevBuf apart;
   u64 agg_padded = 0, agg_distinct_est = 0;
+  bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
+  u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
+  int split_opt = 0;        // 0 = auto, 1 = never, 2..6 = force split_xbits = value - 1
+  u32 hint_xbits = 0;
+  DevBuf seg_off2, ghist2;
   u64 est_fallbacks = 0;  // times an estimated-capacity partition overflowed and the stage was repeated exactly
   u32 xbits = 0;
   DevBuf lpart;
@@ -444,15 +449,38 @@ int repartition_rx(p3_ctx* c) {
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
+  u64* st0 = (u64*)c->dstats.p;
   if (c->n_ranks > 1 && !c->reparted) {
-    if ((rc = c->part_pos ? repartition_rx<u64>(c) : repartition_rx<u32>(c))) return rc;
+    if (c->part_pos && c->est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
+      // position records: the stager-based split with estimated capacities (one launch, no histogram pass); an
+      // overflow is noticed with the count kernel's flags below and repeats this step the exact way
+      u32 xb = 0;
+      while ((1u << xb) < c->n_ranks) xb++;
+      c->xbits = xb;
+      const u32 segcap = segcap_for((double)c->rx_records * 1.02 / ((double)P3_NB * P3_NWG));
+      if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+      if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+      if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
+      HIPCHK(c, hipMemsetAsync(st0 + 26, 0, 8, c->stream));
+      LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
+      const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
+      LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
+                 (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, P3_NB / c->n_ranks, 0u, P3_NB / c->n_ranks, xb,
+                 (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st0 + 26}));
+      c->reparted = true;
+      c->reparted_split = true;
+    } else {
+      if ((rc = c->part_pos ? repartition_rx<u64>(c) : repartition_rx<u32>(c))) return rc;
+      c->reparted_split = false;
+    }
   }
   const u32 xbits = c->n_ranks > 1 ? c->xbits : 0;
   const u32 rows = P3_NB / c->n_ranks;
   const u32 nsb = (xbits ? P3_NB : rows) << sbits;
+  const bool split_desc = xbits && c->reparted_split;
   const void* kpart = xbits ? c->lpart.p : c->rx_part;
-  const void* kseg = xbits ? c->seg_off.p : c->rx_segoff;
-  const void* khist = xbits ? c->ghist.p : c->rx_ghist;
+  const void* kseg = xbits ? (split_desc ? c->seg_off2.p : c->seg_off.p) : c->rx_segoff;
+  const void* khist = xbits ? (split_desc ? c->ghist2.p : c->ghist.p) : c->rx_ghist;
   // worst case one entry per received record
   u64 maxd = c->rx_records + 1;
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
@@ -493,6 +521,11 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     c->est_ok = false;
     c->est_fallbacks++;
+    if (c->n_ranks > 1) {  // the owner-side split is rank-local: redo it exactly, here, and count again
+      c->reparted = false;
+      HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
+      return count_owned(c, sbits, overflowed, max_solid_sb);
+    }
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
   *overflowed = h[3] != 0;
@@ -502,6 +535,68 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   c->cstats.max_count = h[2];
   c->cstats.n_windows = h[5];  // this rank's windows (local partition)
   c->ccounts_u32 = true;
+  return P3_OK;
+}
+
+// (2') single rank, large input: level-1 buckets are split once more (k_split) in 2^xbits groups of 1024 >> xbits
+// buckets, each group giving 1024 cells that the count kernel reads ONCE (or 2^sbits times if a cell still
+// overflows a table) instead of reading every bucket 2^(xbits+sbits) times.  Outputs accumulate over the groups.
+int count_split(p3_ctx* c, u32 xbits, u32 sbits, bool* overflowed, u64* max_solid_sb) {
+  int rc;
+  const u32 groups = 1u << xbits, rows = P3_NB >> xbits;
+  const u32 nsb = P3_NB << sbits;
+  u64 maxd = c->rx_records + 1;
+  if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
+  if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+  if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  const u32 ts_log2 = (u32)c->ts_log2_opt;
+  if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
+  if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
+  if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
+  // records per (cell, workgroup) segment of one group: (windows / groups) / (1024 cells x 256 workgroups)
+  const double mean = (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32) /
+                      ((double)groups * P3_NB * P3_NWG);
+  const u32 segcap = segcap_for(mean);
+  if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
+  LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
+  const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
+  const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
+  for (u32 g = 0; g < groups; g++) {
+    LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
+               (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, g * rows, rows, xbits, (u64*)c->lpart.p,
+               (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+               (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, 1u, rows, g * rows, xbits, sbits, ts_log2,
+               (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
+               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, 0u);
+  }
+  HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+  c->sbits = sbits;
+  c->ccounts_u32 = true;
+  if (c->spec) {
+    *overflowed = false;
+    *max_solid_sb = 0;
+    return P3_OK;
+  }
+  u64 h[32];
+  HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (h[26]) {
+    c->est_ok = false;
+    c->est_fallbacks++;
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+  }
+  *overflowed = h[3] != 0;
+  *max_solid_sb = h[4];
+  c->cstats.n_distinct = h[0];
+  c->cstats.n_solid = h[1];
+  c->cstats.max_count = h[2];
+  c->cstats.n_windows = h[5];
   return P3_OK;
 }
 
@@ -666,13 +761,23 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
   if ((rc = part_local(c, with_pos))) return rc;
   if ((rc = set_rx_local(c))) return rc;
   u64 max_solid = 0;
-  for (u32 sbits = initial_sbits(c->n_words * 32);; sbits++) {
+  // A 4-way split (sbits = 2) still reads every bucket four times; from 8-way on the second-level partition pays
+  u32 first = initial_sbits(c->n_words * 32);
+  c->split_xbits = 0;
+  if (with_pos && c->part_est && c->split_opt != 1) {
+    if (c->split_opt >= 2) c->split_xbits = (u32)c->split_opt - 1;
+    else if (first >= 3) c->split_xbits = first < 4 ? 4 : first;
+    if (c->split_xbits) first = 0;
+  }
+  for (u32 sbits = first;; sbits++) {
     if (sbits > 5) {
       *overflowed = true;
       return P3_OK;
     }
     bool ovf = false;
-    if ((rc = count_owned(c, sbits, &ovf, &max_solid))) return rc;
+    if ((rc = c->split_xbits ? count_split(c, c->split_xbits, sbits, &ovf, &max_solid)
+                             : count_owned(c, sbits, &ovf, &max_solid)))
+      return rc;
     if (!ovf) break;
   }
   if (with_pos) return solid_bits(c, (const u32*)c->singles.p, (const u64*)c->sing_cursor.p, c->sing_count[0]);
@@ -1066,7 +1171,8 @@ int p3_destroy(p3_ctx* c) {
                     &c->ghist, &c->seg_off, &c->bucket_count, &c->part, &c->sb_info, &c->solid, &c->kpart, &c->dkeys, &c->ppart, &c->rx_roff, &c->rx_part_buf, &c->rx_ghist_buf, &c->rx_segoff_buf,
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
-                    &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys};
+                    &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
+                    &c->ghist2};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1105,6 +1211,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "count_split") {
+    if (value < 0 || value > 6) return fail(c, P3_EBADARG, "count_split must be in [0,6]");
+    c->split_opt = (int)value;
   } else if (n == "mr_aggregate") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
     c->agg_opt = (int)value;
@@ -1128,6 +1237,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
+  else if (n == "split_xbits") *value = c->split_xbits;
   else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
@@ -1690,7 +1800,10 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
       if ((rc = set_rx_local(c))) break;
       bool ovf = false;
       u64 mx = 0;
-      if ((rc = count_owned(c, c->hint_sbits, &ovf, &mx))) break;
+      c->split_xbits = c->hint_xbits;
+      if ((rc = c->split_xbits ? count_split(c, c->split_xbits, c->hint_sbits, &ovf, &mx)
+                               : count_owned(c, c->hint_sbits, &ovf, &mx)))
+        break;
       if ((rc = solid_bits(c, (const u32*)c->singles.p, (const u64*)c->sing_cursor.p, c->n_words * 32))) break;
       HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
       rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
@@ -1715,6 +1828,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     c->hint_valid = true;
     c->hint_epoch = c->reads_epoch;
     c->hint_sbits = c->sbits;
+    c->hint_xbits = c->split_xbits;
     c->hint_ksbits = c->ksbits;
     c->hint_nsing = c->sing_count[0];
     c->hint_k = k;

@@ -448,3 +448,24 @@ def test_speculative_pass_survives_stale_hints(oracle):
         c.run_pass(k, m, H)
         check(c, b, o, k, m, H)
     c.close()
+
+
+@pytest.mark.parametrize("split,k", [(2, 31), (3, 31), (5, 25), (6, 41)])
+def test_second_level_partition(oracle, split, k):
+    """count_split = x+1 forces the large-input form of the count stage (k_split: level-1 buckets split once more
+    into 1024 cells per group of 1024 >> x buckets, counted group by group) on an input small enough for the oracle."""
+    b, o = synth.reads(seed=31 + split, total_reads=30000, read_len=150)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    c.set_option("count_split", split)
+    run_and_compare(c, oracle, (b, o), k, m, H)
+    assert c.get_info("split_xbits") == split - 1 and c.get_info("count_mode") == 2 and c.get_info("gate_mode") == 2
+    c.run_pass(k, m, H)   # careful pass, then the speculative one with the remembered split
+    c.run_pass(k, m, H)
+    assert c.get_info("split_xbits") == split - 1
+    keys, counts = c.export_counts()
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+    ebloom, _, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    assert np.array_equal(c.export_bloom(), ebloom)
+    c.close()
