@@ -253,25 +253,37 @@ def test_config2_full_size_against_reference_checksums(ctx):
         assert ctx.bloom_query(np.minimum(samp, rc)).all()
 
 
-@pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3)])
+@pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3),
+                                              (4, 31, 2, 10), (2, 29, 2, 11)])
 def test_multirank_loopback(oracle, world, k, gate, agg):
     """The REAL multi-rank protocol (HIP kernels, n_ranks = 2/4/8) on one GPU: `world` contexts driven by threads,
     exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads.
     agg: 1 = senders pre-aggregate their 21-mer records (forced), 0 = raw instance records, 2 = even ranks only,
-    3 = the library decides from its sampled estimate of the rank's distinct keys (the default)."""
+    3 = the library decides from its sampled estimate of the rank's distinct keys (the default);
+    10 / 11 = raw / aggregated with SKEWED reads (a third of them low-complexity repeats): the owners' estimated-capacity
+    split overflows and must repeat itself exactly, on that rank only."""
     import threading
     from loopback_comm import LoopbackWorld
     from platanus3_amd.pipeline import Pipeline
     n_reads = 24000
     per = n_reads // world
     b, o = synth.reads(seed=41, total_reads=n_reads, read_len=150)
+    skew = agg >= 10
+    if skew:
+        agg = agg - 10   # 0 = raw, 1 = forced aggregation
+        b = b.copy()
+        units = [b"A", b"AC", b"ACG", b"AAC", b"ACGT"]
+        for i in range(0, n_reads, 3):
+            u = units[(i // 3) % len(units)]
+            b[int(o[i]):int(o[i + 1])] = np.frombuffer((u * 160)[:150], dtype=np.uint8)
     m, H = oracle.estimate_bloom(n_reads * 150, k)
     lw = LoopbackWorld(world)
     results, errors = [None] * world, []
 
     def worker(r):
         try:
-            bb, oo = synth.reads(seed=41, total_reads=n_reads, first_read=r * per, n_reads=per, read_len=150)
+            bb = b[int(o[r * per]):int(o[(r + 1) * per])]
+            oo = o[r * per:(r + 1) * per + 1] - o[r * per]
             pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
             pipe.ctx.set_option("gate_mode", gate)
             want_agg = agg == 1 or (agg == 2 and r % 2 == 0)
@@ -283,7 +295,8 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
                 assert c.get_info("mr_aggregated") == (1 if (want_agg and gate == 2) else 0)
             c.k, c.m, c.H = k, m, H
             keys, counts = c.export_counts()
-            results[r] = (keys.copy(), counts.copy(), c.export_bloom(), [capi.decode_key(x, k) for x in c.export_seeds()])
+            results[r] = (keys.copy(), counts.copy(), c.export_bloom(), [capi.decode_key(x, k) for x in c.export_seeds()],
+                          c.get_info("est_fallbacks"))
             c.close()
         except Exception as e:  # noqa: BLE001
             errors.append(e)
@@ -305,6 +318,8 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
     for r in results:
         assert np.array_equal(r[2], ebloom)
     assert sorted(set(s for r in results for s in r[3])) == eseeds
+    if skew and gate == 2:
+        assert sum(r[4] for r in results) >= 1
 
 
 def test_beyond_2g_bases_uses_direct_kernels_and_keeps_the_invariants():
