@@ -446,38 +446,41 @@ int repartition_rx(p3_ctx* c) {
   return P3_OK;
 }
 
+int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb);
+
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
-  u64* st0 = (u64*)c->dstats.p;
-  if (c->n_ranks > 1 && !c->reparted) {
-    if (c->part_pos && c->est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
-      // position records: the stager-based split with estimated capacities (one launch, no histogram pass); an
-      // overflow is noticed with the count kernel's flags below and repeats this step the exact way
-      u32 xb = 0;
-      while ((1u << xb) < c->n_ranks) xb++;
-      c->xbits = xb;
-      const u32 segcap = segcap_for((double)c->rx_records * 1.02 / ((double)P3_NB * P3_NWG));
-      if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
-      if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
-      if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
-      HIPCHK(c, hipMemsetAsync(st0 + 26, 0, 8, c->stream));
-      LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
-      const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
-      LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
-                 (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, c->n_ranks, P3_NB / c->n_ranks, 0u, P3_NB / c->n_ranks, xb,
-                 (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st0 + 26}));
-      c->reparted = true;
-      c->reparted_split = true;
-    } else {
-      if ((rc = c->part_pos ? repartition_rx<u64>(c) : repartition_rx<u32>(c))) return rc;
-      c->reparted_split = false;
+  if (c->n_ranks > 1 && c->part_pos && c->est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
+    // position records: owner-side split through the stager with estimated capacities (k_split; no histogram pass).
+    // From an 8-way sub-bucket split on, the owned buckets are processed in 2^xg groups with xg more split bits
+    // instead, so that every cell is read once.  An overflow of the estimate clears est_ok and lands in the exact
+    // form below.
+    u32 xg = 0, sb_int = sbits;
+    if (c->split_opt >= 2) xg = (u32)c->split_opt - 1;
+    else if (c->split_opt != 1 && sbits >= 3) xg = sbits;
+    if (xg) sb_int = 0;
+    u32 lg = 0;
+    while ((1u << lg) < c->n_ranks) lg++;
+    if (lg + xg <= P3_PBITS) {
+      c->xbits = lg;
+      rc = count_split(c, xg, sb_int, overflowed, max_solid_sb);
+      if (rc != P3_ERETRY_INTERNAL) {
+        c->sbits = sbits;
+        return rc;
+      }
+      c->reparted = false;  // est_ok is false now: fall through to the exact re-partition
+      HIPCHK(c, hipMemsetAsync((u64*)c->dstats.p + 26, 0, 8, c->stream));
     }
+  }
+  if (c->n_ranks > 1 && !c->reparted) {
+    if ((rc = c->part_pos ? repartition_rx<u64>(c) : repartition_rx<u32>(c))) return rc;
+    c->reparted_split = false;
   }
   const u32 xbits = c->n_ranks > 1 ? c->xbits : 0;
   const u32 rows = P3_NB / c->n_ranks;
   const u32 nsb = (xbits ? P3_NB : rows) << sbits;
-  const bool split_desc = xbits && c->reparted_split;
+  const bool split_desc = false;
   const void* kpart = xbits ? c->lpart.p : c->rx_part;
   const void* kseg = xbits ? (split_desc ? c->seg_off2.p : c->seg_off.p) : c->rx_segoff;
   const void* khist = xbits ? (split_desc ? c->ghist2.p : c->ghist.p) : c->rx_ghist;
@@ -521,11 +524,6 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     c->est_ok = false;
     c->est_fallbacks++;
-    if (c->n_ranks > 1) {  // the owner-side split is rank-local: redo it exactly, here, and count again
-      c->reparted = false;
-      HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
-      return count_owned(c, sbits, overflowed, max_solid_sb);
-    }
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
   *overflowed = h[3] != 0;
@@ -538,12 +536,20 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   return P3_OK;
 }
 
-// (2') single rank, large input: level-1 buckets are split once more (k_split) in 2^xbits groups of 1024 >> xbits
-// buckets, each group giving 1024 cells that the count kernel reads ONCE (or 2^sbits times if a cell still
-// overflows a table) instead of reading every bucket 2^(xbits+sbits) times.  Outputs accumulate over the groups.
-int count_split(p3_ctx* c, u32 xbits, u32 sbits, bool* overflowed, u64* max_solid_sb) {
+// (2') second-level partition + count.  Single rank, large input: the 1024 level-1 buckets are split once more
+// (k_split) in 2^xg groups of 1024 >> xg buckets, each group giving 1024 cells that the count kernel reads ONCE (or
+// 2^sbits times if a cell still overflows a table) instead of reading every bucket 2^(xg+sbits) times.  Multi-rank
+// owner: the same over its 1024 / N received buckets from N sources, log2(N) + xg split bits per group.  Outputs
+// accumulate over the groups.
+int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
-  const u32 groups = 1u << xbits, rows = P3_NB >> xbits;
+  const bool mr = c->n_ranks > 1;
+  const u32 n_src = mr ? c->n_ranks : 1u;
+  u32 lg = 0;
+  while ((1u << lg) < n_src) lg++;
+  const u32 rows_total = P3_NB / n_src, xbits = lg + xg;
+  const u32 groups = 1u << xg, rows = rows_total >> xg;
+  const u32 first_pb = mr ? c->rank * rows_total : 0u;
   const u32 nsb = P3_NB << sbits;
   u64 maxd = c->rx_records + 1;
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
@@ -553,29 +559,30 @@ int count_split(p3_ctx* c, u32 xbits, u32 sbits, bool* overflowed, u64* max_soli
   if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
   if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
   if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
   HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
-  // records per (cell, workgroup) segment of one group: (windows / groups) / (1024 cells x 256 workgroups)
-  const double mean = (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32) /
-                      ((double)groups * P3_NB * P3_NWG);
-  const u32 segcap = segcap_for(mean);
+  // records per (cell, workgroup) segment of one group: (records / groups) / (1024 cells x 256 workgroups)
+  const double total = mr ? (double)c->rx_records * 1.02
+                          : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
+  const u32 segcap = segcap_for(total / ((double)groups * P3_NB * P3_NWG));
   if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
   LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
   for (u32 g = 0; g < groups; g++) {
     LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
-               (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, g * rows, rows, xbits, (u64*)c->lpart.p,
-               (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
+               (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, rows_total, g * rows, rows, xbits,
+               (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
-               (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, 1u, rows, g * rows, xbits, sbits, ts_log2,
+               (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, 0u);
+               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
   }
-  HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
   c->ccounts_u32 = true;
   if (c->spec) {
@@ -761,12 +768,13 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
   if ((rc = part_local(c, with_pos))) return rc;
   if ((rc = set_rx_local(c))) return rc;
   u64 max_solid = 0;
-  // A 4-way split (sbits = 2) still reads every bucket four times; from 8-way on the second-level partition pays
+  // A 4-way split (every bucket read four times) still beats the extra pass (2 M reads: 6.3 vs 6.6 ms); from 8-way
+  // on the second-level partition pays (3 M reads: 9.9 vs 11.1 ms; 6.25 M: 22.0 vs 32.8 ms)
   u32 first = initial_sbits(c->n_words * 32);
   c->split_xbits = 0;
   if (with_pos && c->part_est && c->split_opt != 1) {
     if (c->split_opt >= 2) c->split_xbits = (u32)c->split_opt - 1;
-    else if (first >= 3) c->split_xbits = first < 4 ? 4 : first;
+    else if (first >= 3) c->split_xbits = first;
     if (c->split_xbits) first = 0;
   }
   for (u32 sbits = first;; sbits++) {

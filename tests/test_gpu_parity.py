@@ -254,7 +254,7 @@ def test_config2_full_size_against_reference_checksums(ctx):
 
 
 @pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3),
-                                              (4, 31, 2, 10), (2, 29, 2, 11)])
+                                              (4, 31, 2, 10), (2, 29, 2, 11), (4, 31, 2, 20), (2, 33, 2, 21), (8, 31, 2, 20)])
 def test_multirank_loopback(oracle, world, k, gate, agg):
     """The REAL multi-rank protocol (HIP kernels, n_ranks = 2/4/8) on one GPU: `world` contexts driven by threads,
     exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads.
@@ -268,6 +268,9 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
     n_reads = 24000
     per = n_reads // world
     b, o = synth.reads(seed=41, total_reads=n_reads, read_len=150)
+    split = 0
+    if agg >= 20:   # 20 / 21 = raw / aggregated, owners count in groups with extra split bits (large-input form)
+        split, agg = 3, agg - 20
     skew = agg >= 10
     if skew:
         agg = agg - 10   # 0 = raw, 1 = forced aggregation
@@ -286,6 +289,8 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
             oo = o[r * per:(r + 1) * per + 1] - o[r * per]
             pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
             pipe.ctx.set_option("gate_mode", gate)
+            if split:
+                pipe.ctx.set_option("count_split", split)
             want_agg = agg == 1 or (agg == 2 and r % 2 == 0)
             pipe.ctx.set_option("mr_aggregate", 1 if agg == 3 else (2 if want_agg else 0))
             pipe.load_reads(bb, oo, min_len=k)

@@ -28,8 +28,10 @@ for sh in shapes:
     m, H = bloom_sizing(int(b.size), k)
     print(f"== {sh}: {b.size/1e6:.0f} Mbases m={m} H={H} (synth {time.time()-t0:.1f}s)", flush=True)
     res = {}
-    for mode in ("fast", "direct"):
+    for mode in ("fast", "nosplit", "direct"):
         c = capi.Context(0)
+        if mode == "nosplit":
+            c.set_option("count_split", 1)
         if mode == "direct":
             c.set_option("count_mode", 1)
             c.set_option("bloom_mode", 1)
@@ -47,7 +49,7 @@ for sh in shapes:
         info = {n: c.get_info(n) for n in ("count_mode", "gate_mode", "bloom_mode", "sbits", "ksbits")}
         nk = (L - k + 1) * R
         print(f"   {mode}: load {t1-t0:.2f}s pass {tm['ms_total']:.2f} ms = {nk/tm['ms_total']/1e6:.2f} G k-mers/s  {info}", flush=True)
-        if mode == "fast":
+        if mode in ("fast", "nosplit"):
             c.reset_kernel_stats(); c.set_profiling(True)
             c.run_pass(k, m, H)
             c.set_profiling(False)
@@ -57,5 +59,4 @@ for sh in shapes:
         res[mode] = digest(c)
         print(f"   {mode}: {res[mode]} (export {time.time()-t0:.1f}s)", flush=True)
         c.close()
-    if len(res) == 2:
-        print("   MATCH" if res["fast"] == res["direct"] else "   *** MISMATCH ***", flush=True)
+    print("   MATCH" if all(r == res["fast"] for r in res.values()) else "   *** MISMATCH ***", flush=True)
