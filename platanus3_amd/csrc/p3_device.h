@@ -88,6 +88,47 @@ __device__ __forceinline__ u64 std_hash_key(u64 lo, u64 hi, u32 k) {
   return h;
 }
 
+// Sliding-window OR / AND over a 128-bit bit string (hi:lo), bit-parallel: bit p (p < 32) of the result combines
+// bits p .. p+n-1 of the input, 1 <= n <= 64.  Log-step doubling (OR and AND are idempotent, so the last, shorter
+// step may overlap): ~2 log2(n) 64-bit operations for all 32 window starts of a stream word at once, instead of a
+// mask test and a 128-bit shift per window.
+__device__ __forceinline__ void shr128_by(u64& lo, u64& hi, u32 s) {  // 0 < s < 64
+  lo = (lo >> s) | (hi << (64 - s));
+  hi >>= s;
+}
+__device__ __forceinline__ u32 win_or32(u64 lo, u64 hi, u32 n) {
+  u32 cov = 1;
+  while (cov * 2 <= n) {
+    u64 a = lo, b = hi;
+    shr128_by(a, b, cov);
+    lo |= a;
+    hi |= b;
+    cov *= 2;
+  }
+  if (cov < n) {
+    u64 a = lo, b = hi;
+    shr128_by(a, b, n - cov);
+    lo |= a;
+  }
+  return (u32)lo;
+}
+__device__ __forceinline__ u32 win_and32(u64 lo, u64 hi, u32 n) {
+  u32 cov = 1;
+  while (cov * 2 <= n) {
+    u64 a = lo, b = hi;
+    shr128_by(a, b, cov);
+    lo &= a;
+    hi &= b;
+    cov *= 2;
+  }
+  if (cov < n) {
+    u64 a = lo, b = hi;
+    shr128_by(a, b, n - cov);
+    lo &= a;
+  }
+  return (u32)lo;
+}
+
 // wave64 ballot on a bool: the HIP ballot64(int) wrapper round-trips the predicate through an integer and costs a
 // v_cndmask + v_cmp per call; this is the lane mask itself
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }

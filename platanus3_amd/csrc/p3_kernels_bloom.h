@@ -290,8 +290,6 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
   __syncthreads();
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
-  const u64 vmask = (1ULL << (k - 1)) - 1;  // k-1 <= 63
-  const u64 smask = (1ULL << (k - 20)) - 1;
   u64 n_valid = 0, n_pass = 0;
   for (u64 w = begin + threadIdx.x; w < end; w += blockDim.x) {
     LaneWords L = load_lane_words(fw, rcw, endm, w);
@@ -299,21 +297,17 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
     u64 Shi = (u64)S[w + 2] | ((u64)S[w + 3] << 32);
     KmerRoll<NW> kr;
     kr.init(k, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
-    u32 pbits = 0;
+    const u32 validk = ~win_or32(L.Elo, L.Ehi, k - 1);
+    const u32 pbits = validk & win_and32(Slo, Shi, k - 20);
+    n_valid += __popc(validk);
+    n_pass += __popc(pbits);
     for (int j = 0; j < 32; j++) {
-      const bool valid = (L.Elo & vmask) == 0;
-      const bool pass = valid && ((~Slo & smask) == 0);
-      n_valid += valid;
-      if (pass) {
-        n_pass++;
-        pbits |= 1u << j;
+      if ((pbits >> j) & 1u) {
         u64 lo, hi;
         kr.canonical(lo, hi);
         atomicAdd(&hist[(u32)(khash<NW>(lo, hi) >> (64 - P3_PBITS))], 1u);
       }
       kr.roll();
-      shr128(L.Elo, L.Ehi);
-      shr128(Slo, Shi);
     }
     P[w] = pbits;
   }
@@ -372,15 +366,9 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
         // pass(p) = window [p,p+k) inside one read AND solid bits p..p+k-21 all set (== RMQ >= 2)
         u64 Elo = (u64)endm[w] | ((u64)endm[w + 1] << 32), Ehi = (u64)endm[w + 2] | ((u64)endm[w + 3] << 32);
         u64 Slo = (u64)S[w] | ((u64)S[w + 1] << 32), Shi = (u64)S[w + 2] | ((u64)S[w + 3] << 32);
-        const u64 vmask = (1ULL << (k - 1)) - 1, smask = (1ULL << (k - 20)) - 1;
-#pragma unroll 8
-        for (int j = 0; j < 32; j++) {
-          const bool valid = (Elo & vmask) == 0;
-          n_valid += valid;
-          if (valid && ((~Slo & smask) == 0)) pbits |= 1u << j;
-          shr128(Elo, Ehi);
-          shr128(Slo, Shi);
-        }
+        const u32 validk = ~win_or32(Elo, Ehi, k - 1);  // no read end in [p, p+k-1)
+        pbits = validk & win_and32(Slo, Shi, k - 20);    // ... and the k-20 solid bits from p on all set
+        n_valid += __popc(validk);
         n_pass += __popc(pbits);
         P[w] = pbits;
       } else {

@@ -84,16 +84,15 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __rest
     LaneWords L = load_lane_words(fw, rcw, endm, w);
     KmerRoll<1> kr;
     kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
-    const u64 vmask = (1ULL << 20) - 1;
+    const u32 vbits = ~win_or32(L.Elo, L.Ehi, 20);  // window p is valid <=> no read end in [p, p+20)
 #pragma unroll 4
     for (int j = 0; j < 32; j++) {
-      if ((L.Elo & vmask) == 0) {
+      if ((vbits >> j) & 1u) {
         u64 lo, hi;
         kr.canonical(lo, hi);
         atomicAdd(&hist[(u32)(mix42(lo) >> 32)], 1u);
       }
       kr.roll();
-      shr128(L.Elo, L.Ehi);
     }
   }
   __syncthreads();

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
   stage_init(stg, seg_off, est);
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
-  const u64 vmask = (1ULL << 20) - 1;
+  u32 vbits = 0;
   u64 base = begin;
   int round = 32 / RW;  // "tile exhausted": the first call loads the first tile
   bool first = true;
@@ -48,12 +48,11 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
       round = 0;
       w = base + threadIdx.x;
       active = w < end;
+      vbits = 0;
       if (active) {
         L = load_lane_words(fw, rcw, endm, w);
         kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
-      } else {
-        L.Elo = ~0ULL;
-        L.Ehi = ~0ULL;
+        vbits = ~win_or32(L.Elo, L.Ehi, 20);  // window p is valid <=> no read end in [p, p+20)
       }
     }
     pend = 0;
@@ -61,7 +60,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
     for (int i = 0; i < RW; i++) {
       rec[i] = 0;
       bkt[i] = 0;
-      if (active && (L.Elo & vmask) == 0) {
+      if ((vbits >> (round * RW + i)) & 1u) {
         u64 lo, hi;
         kr.canonical(lo, hi);
         const u64 g = mix42(lo);
@@ -69,10 +68,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64*
         bkt[i] = (u32)(g >> 32);
         pend |= 1u << i;
       }
-      if (active) {
-        kr.roll();
-        shr128(L.Elo, L.Ehi);
-      }
+      if (active) kr.roll();
     }
     round++;
     return true;
