@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
                                                                   typename KRec<NW>::type* __restrict__ part,
                                                                   EstSeg est, u64* __restrict__ stats) {
   typedef typename KRec<NW>::type REC;
-  constexpr int RW = (NW == 1) ? 4 : 2;  // windows per lane per round: inflow/bucket stays well below CAP
+  constexpr int RW = (NW == 1) ? 4 : 2;  // windows per lane per round: inflow/bucket stays well below CAP (8 was no faster)
   extern __shared__ __align__(16) u32 lds[];
   const StageLds stg = stage_layout(lds);
   u32* cnt = stg.cnt;
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
     return;
   }
   const u64 n = *n_ptr;
-  constexpr int PR = 8;  // probes per lane per round
+  constexpr int PR = 10;  // probes per lane per round (H = 19 -> two rounds per key, H = 10 -> one)
   extern __shared__ __align__(16) u32 lds[];
   const StageLds stg = stage_layout(lds);
   stage_init(stg, seg_off, est);
