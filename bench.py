@@ -171,7 +171,7 @@ def main():
                     "pass_alg_bytes_per_kmer": b_alg_kmer,
                     "pass_frac": (value / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
                     "kernels_ms_per_step": {n: s["total_ms"] for n, s in sorted(split.items())}}
-        out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d" % k, "value": value, "unit": "k-mers/s",
+        out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d; 1/2/4/8 MI355X + %%HBM roofline" % k, "value": value, "unit": "k-mers/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": "%d x %d bp synthetic reads per GPU (%d total, 30x, 0.5%% subst), k=%d, "
