@@ -328,14 +328,14 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
   if (gl == 0) atomicMax(s_maxsteps, my_steps);
   __syncthreads();
   const u32 max_steps = *s_maxsteps;
-  StageCarry<u64> carry;
-  carry.has = false;
-  carry.par = 0;
-  carry.bkt = 0;
-  carry.rec = 0;
   u32 it = grp, vi = 0;  // current item and first vector of the next step
   u32 cnt = it < n_items ? item_cnt[it] : 0, off = it < n_items ? item_off[it] : 0;
-  for (u32 step = 0; step < max_steps; step++) {
+  u32 step = 0;
+  // software-pipelined (stage_run): the loads of step s+1 are issued between the two barriers of step s, so their
+  // latency hides behind the flush instead of stalling every round
+  stage_run<u64, 4>(stg, out, est, [&](u64 (&rec)[4], u32 (&bkt)[4], u32& pend) -> bool {
+    if (step >= max_steps) return false;
+    step++;
     while (it < n_items && vi * 2 >= cnt) {  // item exhausted (or empty): next one of this group
       it += ngroups;
       vi = 0;
@@ -344,9 +344,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
         off = item_off[it];
       }
     }
-    u64 rec[4];
-    u32 bkt[4];
-    u32 pend = 0;
+    pend = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       rec[t] = 0;
@@ -373,7 +371,6 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
       }
       vi += 2 * GL;
     }
-    stage_round<u64, 4>(stg, out, est, rec, bkt, pend, carry);
-  }
-  stage_finish<u64>(stg, out, est, carry);
+    return true;
+  });
 }
