@@ -721,7 +721,8 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
 // writes it in this mode).  n_u32 = number of u32 words of the whole vector.
 __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
-                                                       u32* __restrict__ bloom, const u64* __restrict__ cap_flag) {
+                                                       u32* __restrict__ bloom, const u64* __restrict__ cap_flag,
+                                                       u32 accumulate) {
   if (*cap_flag) return;  // the probe partition did not fit: the host repeats the stage
   extern __shared__ __align__(16) u32 lds[];
   const u32 words = 1u << (slice_log2 - 5);
@@ -739,5 +740,5 @@ __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ p
   __syncthreads();
   const u64 w0 = (u64)s * words;
   for (u32 i = threadIdx.x; i < words; i += blockDim.x)
-    if (w0 + i < n_u32) bloom[w0 + i] = bm[i];
+    if (w0 + i < n_u32) bloom[w0 + i] = accumulate ? (bloom[w0 + i] | bm[i]) : bm[i];  // accumulate: later position chunks
 }

@@ -305,8 +305,12 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                      u64* __restrict__ gstats, u64* __restrict__ tpairs,
                                                      u32* __restrict__ singles,
-                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode) {
+                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode,
+                                                     const u64* __restrict__ sroff) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
+  // sroff: where each source's list of single-instance positions starts in `singles` (null: same as roff, the
+  // record offsets of the sources -- the lists then sit at the start of the sources' own regions)
+  if (!sroff) sroff = roff;
   // mode & P3_K2_WEIGHTED (POS only): the records are locally pre-aggregated -- bit 63 set = "this key occurred
   // (bits 62..32) times at the sender", clear = one instance at window position (bits 62..32).
   // mode & P3_K2_AGG_OUT (POS only): emit such records instead of the table (the sender side of the above).
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         u32 wbase = 0;
         if (lane == 0 && bal) wbase = atomicAdd(&s_sing[0], (u32)__popcll(bal));
         wbase = __shfl(wbase, 0, 64);
-        if (one) singles[roff[0] + s_singbase[0] + wbase + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u32)pr;
+        if (one) singles[sroff[0] + s_singbase[0] + wbase + (u32)__popcll(bal & ((1ULL << lane) - 1))] = (u32)pr;
       }
     } else {
       for (u32 t = threadIdx.x; t < nd; t += blockDim.x) {
@@ -554,7 +558,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
         if (tcnt[(u32)(pr >> 32) & (TS - 1)] == 1) {
           const u32 src = (u32)(pr >> 56);
           const u32 idx = atomicAdd(&s_sing[src], 1u);
-          singles[roff[src] + s_singbase[src] + idx] = (u32)pr;
+          singles[sroff[src] + s_singbase[src] + idx] = (u32)pr;
         }
       }
     }

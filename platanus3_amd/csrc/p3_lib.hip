@@ -90,6 +90,13 @@ struct p3_ctx {
   bool agg = false;          // this rank's send partition is pre-aggregated (apart)
   DevBuf apart;
   u64 agg_padded = 0, agg_distinct_est = 0;
+  // oversized single-GPU inputs: the position space is cut into `chunks` (2, 4 or 8) ranges of <= 2^30 positions that
+  // the count stage treats as sources; gate and Bloom stages then run chunk by chunk
+  u32 chunks = 1;
+  bool chunk_acc = false;    // do_bloom_t: later chunk (keep the Bloom vector, OR into it), no seeds yet
+  int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
+  DevBuf part8c, sroff_d;
+  u64 chunk_w0[9] = {0};
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
   int split_opt = 0;        // 0 = auto, 1 = never, 2..6 = force split_xbits = value - 1
@@ -356,6 +363,15 @@ u64 wg_window_bound(const p3_ctx* c) {
   return per * 32;
 }
 
+// workgroups of the hist/scatter kernels that actually receive stream words (the shares are multiples of 1024 words,
+// so a small input keeps only a few of the 256 busy -- and their segments are that much longer)
+double active_wgs(u64 n_words) {
+  u64 per = (n_words + P3_NWG - 1) / P3_NWG;
+  per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+  const u64 a = per ? (n_words + per - 1) / per : 1;
+  return (double)(a ? a : 1);
+}
+
 int fixed_segoff(p3_ctx* c, u32 segcap) {
   LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off.p, segcap);
   return P3_OK;
@@ -382,7 +398,7 @@ int part_local(p3_ctx* c, bool with_pos) {
   const bool est = with_pos && est_mode(c);
   // mean records per (bucket, workgroup) segment: exact window count when the host saw the offsets, else the
   // stream-word bound
-  const double mean21 = c->host_windows ? (double)c->host_windows * 1.02 / ((double)P3_NB * P3_NWG)
+  const double mean21 = c->host_windows ? (double)c->host_windows * 1.02 / ((double)P3_NB * active_wgs(c->n_words))
                                         : (double)wg_window_bound(c) / P3_NB;
   const u32 segcap = est ? segcap_for(mean21) : 0;
   if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
@@ -502,14 +518,14 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
-               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u), (const u64*)nullptr);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u, (const u64*)nullptr);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -543,11 +559,11 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
 // accumulate over the groups.
 int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
-  const bool mr = c->n_ranks > 1;
-  const u32 n_src = mr ? c->n_ranks : 1u;
-  u32 lg = 0;
-  while ((1u << lg) < n_src) lg++;
-  const u32 rows_total = P3_NB / n_src, xbits = lg + xg;
+  const bool mr = c->n_ranks > 1, chunked = !mr && c->chunks > 1;
+  const u32 n_src = mr ? c->n_ranks : (chunked ? c->chunks : 1u);
+  u32 lg = 0;  // split bits that come from the owner's share of the buckets (multi-rank only)
+  while (mr && (1u << lg) < n_src) lg++;
+  const u32 rows_total = mr ? P3_NB / n_src : (u32)P3_NB, xbits = lg + xg;
   const u32 groups = 1u << xg, rows = rows_total >> xg;
   const u32 first_pb = mr ? c->rank * rows_total : 0u;
   const u32 nsb = P3_NB << sbits;
@@ -566,8 +582,8 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
   HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
   // records per (cell, workgroup) segment of one group: (records / groups) / (1024 cells x 256 workgroups)
-  const double total = mr ? (double)c->rx_records * 1.02
-                          : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
+  const double total = (mr || chunked) ? (double)c->rx_records * 1.02
+                                       : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
   const u32 segcap = segcap_for(total / ((double)groups * P3_NB * P3_NWG));
   if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
   LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
@@ -575,12 +591,13 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
   for (u32 g = 0; g < groups; g++) {
     LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
-               (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, rows_total, g * rows, rows, xbits,
+               (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, mr ? rows_total : (u32)P3_NB, g * rows, rows, xbits,
                (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u),
+               (const u64*)(chunked ? c->sroff_d.p : nullptr));
   }
   HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
@@ -723,7 +740,7 @@ int agg_local(p3_ctx* c) {
   LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
              (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
              sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
-             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT, (const u64*)nullptr);
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
@@ -739,7 +756,7 @@ int agg_local(p3_ctx* c) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
                (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
                (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
-               (u32)P3_K2_AGG_OUT);
+               (u32)P3_K2_AGG_OUT, (const u64*)nullptr);
     HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h[3]) break;
@@ -792,10 +809,166 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
   return solid_build(c, rs_log2_for(max_solid));
 }
 
+
+// ---- oversized single-GPU inputs: position chunks -----------------------------------------------------------------
+// Records address a window by a 30-bit position, so one partition covers at most 2^30 positions.  A larger input
+// (up to 8 x 2^30 positions) is cut into 2, 4 or 8 word ranges; each range is partitioned on its own (positions
+// relative to the range), the count kernel takes the ranges as SOURCES -- exactly as it takes the ranks of the
+// multi-rank protocol: first instances are credited per source, so the non-solid positions come back per range --
+// and the gate and Bloom stages then run range by range on narrowed views of the stream buffers.
+struct ChunkView {
+  p3_ctx* c;
+  DevBuf fw, rcw, endm, S, P, part8;
+  u64 n_words, host_windows;
+  explicit ChunkView(p3_ctx* c_) : c(c_), fw(c_->fw), rcw(c_->rcw), endm(c_->endm), S(c_->S), P(c_->P), part8(c_->part8),
+                                   n_words(c_->n_words), host_windows(c_->host_windows) {}
+  static void narrow(DevBuf& dst, const DevBuf& full, u64 w0, size_t elem) {
+    if (!full.p) return;
+    dst.p = (char*)full.p + w0 * elem;
+    dst.bytes = full.bytes - w0 * elem;
+  }
+  void set(u32 ci) {
+    const u64 w0 = c->chunk_w0[ci], nw = c->chunk_w0[ci + 1] - w0;
+    narrow(c->fw, fw, w0, 8);
+    narrow(c->rcw, rcw, w0, 8);
+    narrow(c->endm, endm, w0, 4);
+    narrow(c->S, S, w0, 4);
+    narrow(c->P, P, w0, 4);
+    c->n_words = nw;
+    c->host_windows = host_windows ? (u64)((double)host_windows * (double)nw / (double)n_words) + 1 : 0;
+  }
+  void restore() {
+    c->fw = fw;
+    c->rcw = rcw;
+    c->endm = endm;
+    c->S = S;
+    c->P = P;
+    c->part8 = part8;
+    c->n_words = n_words;
+    c->host_windows = host_windows;
+  }
+  ~ChunkView() { restore(); }
+};
+
+u32 chunks_for(const p3_ctx* c) {  // 0 = the chunked form does not apply
+  if (c->chunk_opt == 1 || c->n_ranks != 1 || c->protocol || !c->est_ok || c->sizing_opt == 1) return 0;
+  if (c->count_mode_opt == 1 || c->gate_mode_opt == 1 || c->bloom_mode_opt == 1) return 0;
+  const u64 pos = c->n_words * 32;
+  if (c->chunk_opt >= 2) return (pos / (u32)c->chunk_opt <= (1ull << 30)) ? (u32)c->chunk_opt : 0;
+  if (pos <= (1ull << 30)) return 0;
+  u32 n = 2;
+  while (n < 8 && (pos + n - 1) / n > (1ull << 30)) n <<= 1;
+  return ((pos + n - 1) / n <= (1ull << 30)) ? n : 0;
+}
+
+// count stage over position chunks.  Returns P3_ERETRY_INTERNAL when an estimate overflowed (the caller then uses
+// the direct kernels); *overflowed as in do_count_part.
+int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
+  int rc;
+  *overflowed = false;
+  c->chunks = C;
+  const u64 wc = (c->n_words + C - 1) / C;
+  for (u32 ci = 0; ci <= C; ci++) c->chunk_w0[ci] = (u64)ci * wc < c->n_words ? (u64)ci * wc : c->n_words;
+  // every chunk gets the same region size: capacity of the first (largest) chunk
+  const double hw0 = c->host_windows ? (double)c->host_windows * (double)wc / (double)c->n_words : 0.0;
+  u64 per = (wc + P3_NWG - 1) / P3_NWG;
+  per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+  const double mean21 = hw0 > 0 ? (hw0 + 1) * 1.02 / ((double)P3_NB * active_wgs(wc)) : (double)(per * 32) / P3_NB;
+  const u64 region = (u64)P3_NB * P3_NWG * (segcap_for(mean21) + 16);  // records per chunk partition (a little slack)
+  const size_t desc = (size_t)P3_NB * P3_NWG * 4;
+  if ((rc = ensure(c, c->part8c, (u64)C * region * 8))) return rc;
+  if ((rc = ensure(c, c->rx_ghist_buf, (size_t)C * desc))) return rc;
+  if ((rc = ensure(c, c->rx_segoff_buf, (size_t)C * desc))) return rc;
+  if ((rc = ensure(c, c->rx_roff, 8 * (P3_MAX_RANKS + 1)))) return rc;
+  if ((rc = ensure(c, c->sroff_d, 8 * (P3_MAX_RANKS + 1)))) return rc;
+  u64 roff[P3_MAX_RANKS + 1] = {0}, sroff[P3_MAX_RANKS + 1] = {0}, windows[8] = {0};
+  u64 total = 0;
+  {
+    ChunkView view(c);
+    for (u32 ci = 0; ci < C; ci++) {
+      view.set(ci);
+      c->part8.p = (char*)c->part8c.p + (u64)ci * region * 8;
+      c->part8.bytes = region * 8;
+      if ((rc = part_local(c, true))) return rc;
+      if (!c->part_est) return fail(c, P3_ERETRY_INTERNAL, "position chunks need the estimated-capacity partition");
+      HIPCHK(c, hipMemcpyAsync((char*)c->rx_ghist_buf.p + ci * desc, c->ghist.p, desc, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync((char*)c->rx_segoff_buf.p + ci * desc, c->seg_off.p, desc, hipMemcpyDeviceToDevice, c->stream));
+      u64 h[32];
+      HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (h[26]) {
+        c->est_ok = false;
+        c->est_fallbacks++;
+        return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+      }
+      windows[ci] = h[5];
+      roff[ci] = (u64)ci * region;
+      sroff[ci] = total;
+      total += windows[ci];
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(c->rx_roff.p, roff, 8 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->sroff_d.p, sroff, 8 * C, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (roff / sroff live on this stack frame)
+  c->rx_part = c->part8c.p;
+  c->rx_ghist = c->rx_ghist_buf.p;
+  c->rx_segoff = c->rx_segoff_buf.p;
+  c->rx_records = total;
+  c->rx_weighted = false;
+  c->part_pos = true;
+  // split bits: cells of <= ~96 Ki records (uncapped version of initial_sbits), at least log2(C) so that the split
+  // kernel's item list (rows x sources) stays within 1024
+  u32 xg = 0;
+  while (xg < 10 && (total >> xg) / P3_NB > 98304) xg++;
+  while ((1u << xg) < C) xg++;
+  u64 max_solid = 0;
+  for (u32 sbits = 0;; sbits++) {
+    if (sbits > 5) {
+      *overflowed = true;
+      return P3_OK;
+    }
+    bool ovf = false;
+    if ((rc = count_split(c, xg, sbits, &ovf, &max_solid))) return rc;
+    if (!ovf) break;
+  }
+  c->split_xbits = xg;
+  c->cstats.n_windows = total;
+  // gate: the non-solid positions of chunk ci are relative to its first word
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  if ((rc = ensure(c, c->S, nwa * 4))) return rc;
+  {
+    ChunkView view(c);
+    for (u32 ci = 0; ci < C; ci++) {
+      view.set(ci);
+      if ((rc = solid_bits(c, (const u32*)c->singles.p + sroff[ci], (const u64*)c->sing_cursor.p + ci, c->sing_count[ci])))
+        return rc;
+      u64 h[32];
+      HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (h[26]) {
+        c->est_ok = false;
+        c->est_fallbacks++;
+        return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+      }
+    }
+  }
+  return P3_OK;
+}
+
 int do_count(p3_ctx* c) {
   int rc;
   if ((rc = ensure(c, c->dstats, 32 * 8))) return rc;
-  const bool can_part = part_applicable(c);
+  c->chunks = 1;
+  const u32 nch = chunks_for(c);
+  if (nch) {
+    bool ovf = false;
+    rc = do_count_chunked(c, nch, &ovf);
+    if (rc == P3_OK && !ovf) return P3_OK;
+    c->chunks = 1;
+    if (rc != P3_OK && rc != P3_ERETRY_INTERNAL) return rc;
+    // an estimate overflowed or a table did at every split: the direct kernels below take over
+  }
+  const bool can_part = part_applicable(c) && !nch;
   if (c->count_mode_opt == 2 && !can_part) return fail(c, P3_EBADARG, "partitioned count forced but input too large");
   if (c->count_mode_opt != 1 && can_part) {
     bool ovf = false;
@@ -824,7 +997,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   const bool have_s = c->count_mode == 2 && c->gate_mode == 2 && c->s_ready;
   if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
+  if (!c->chunk_acc) HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (have_s) {
@@ -849,8 +1022,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     // form serves the multi-rank protocol as well
     const bool est = c->est_ok && c->sizing_opt != 1;
     double mean_k = (double)wg_window_bound(c) / P3_NB;
-    if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * P3_NWG);
-    if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * P3_NWG);
+    if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
+    if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
     const u32 segcap_k = est ? segcap_for(mean_k) : 0;
     if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
@@ -936,7 +1109,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
         LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
                    (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
-                   (const u64*)(st + 24));
+                   (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u));
         c->bloom_mode = 3;
       } else {
         LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H,
@@ -956,8 +1129,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     c->bloom_mode = 1;
   }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
-         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  if (c->chunks == 1)  // (position chunks: the seeds need the pass bits of ALL chunks; bloom_chunked runs them at the end)
+    LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
+           (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 hall[32];
   HIPCHK(c, hipMemcpyAsync(hall, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
@@ -1118,6 +1292,44 @@ int build_graph_t(p3_ctx* c) {
   return P3_OK;
 }
 
+// Bloom stage over position chunks: every chunk partitions, deduplicates and inserts ITS passing k-mers (a k-mer that
+// passes in several chunks is inserted more than once, which a Bloom vector does not notice); the seeds, which need
+// the pass bits of all chunks, come last.
+template <int NW>
+int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
+  int rc;
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  if ((rc = ensure(c, c->S, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->P, nwa * 4))) return rc;
+  u64 nv = 0, np = 0, nd = 0;
+  {
+    ChunkView view(c);
+    for (u32 ci = 0; ci < c->chunks; ci++) {
+      view.set(ci);
+      c->chunk_acc = ci > 0;
+      rc = do_bloom_t<NW>(c, k, m, H);
+      c->chunk_acc = false;
+      if (rc) return rc;
+      nv += c->bstats.n_windows_k;
+      np += c->bstats.n_passing;
+      nd += c->n_distinct_k;
+    }
+  }
+  u64* st = (u64*)c->dstats.p;
+  HIPCHK(c, hipMemsetAsync(st + 10, 0, 8, c->stream));
+  LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
+         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  u64 ns = 0;
+  HIPCHK(c, hipMemcpyAsync(&ns, st + 10, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->bstats.n_windows_k = nv;
+  c->bstats.n_passing = np;
+  c->bstats.n_seed_reads = ns;
+  c->n_distinct_k = nd;
+  return P3_OK;
+}
+
 int check_k(p3_ctx* c, u32 k) {
   if (k < 21 || k > 64) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,64]", k);
   return P3_OK;
@@ -1180,7 +1392,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
-                    &c->ghist2};
+                    &c->ghist2, &c->part8c, &c->sroff_d};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1219,6 +1431,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "chunks") {
+    if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return fail(c, P3_EBADARG, "chunks must be 0, 1, 2, 4 or 8");
+    c->chunk_opt = (int)value;
   } else if (n == "count_split") {
     if (value < 0 || value > 6) return fail(c, P3_EBADARG, "count_split must be in [0,6]");
     c->split_opt = (int)value;
@@ -1246,6 +1461,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
   else if (n == "split_xbits") *value = c->split_xbits;
+  else if (n == "chunks") *value = c->chunks;
   else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
@@ -1689,7 +1905,11 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     return fail(c, P3_ECOUNT_OVERFLOW, "a 21-mer count (%llu) >= 2^31: reference RMQ would truncate",
                 (unsigned long long)c->cstats.max_count);
   HIPCHK(c, hipSetDevice(c->device));
-  rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+  auto bloom_once = [&]() {
+    if (c->chunks > 1) return nw_of(k) == 1 ? bloom_chunked<1>(c, k, m_bits, H) : bloom_chunked<2>(c, k, m_bits, H);
+    return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+  };
+  rc = bloom_once();
   if (rc == P3_ERETRY_INTERNAL) {
     // an estimated-capacity partition overflowed: repeat with exact offsets (the count stage too if its
     // solid-window partition was the one that overflowed; never the case under the multi-rank protocol, whose
@@ -1700,7 +1920,7 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
       if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);
       if (rc) return rc == P3_ERETRY_INTERNAL ? fail(c, P3_EHIP, "internal retry failed") : rc;
     }
-    rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
+    rc = bloom_once();
   }
   if (rc == P3_ERETRY_INTERNAL) rc = fail(c, P3_EHIP, "internal retry failed");
   return rc;
@@ -1832,7 +2052,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
   if ((rc = p3_make_bloom(c, k, m_bits, H))) return rc;
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
-  if (c->count_mode == 2 && c->gate_mode == 2 && c->bloom_mode == 3) {
+  if (c->count_mode == 2 && c->gate_mode == 2 && c->bloom_mode == 3 && c->chunks == 1) {
     c->hint_valid = true;
     c->hint_epoch = c->reads_epoch;
     c->hint_sbits = c->sbits;

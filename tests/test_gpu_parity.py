@@ -327,49 +327,63 @@ def test_multirank_loopback(oracle, world, k, gate, agg):
         assert sum(r[4] for r in results) >= 1
 
 
-def test_beyond_2g_bases_uses_direct_kernels_and_keeps_the_invariants():
-    """Maximum sizes: 2.16 G bases (> 2^31, so 33-bit base positions) exceed what the partitioned kernels index and
-    go through the direct global-table kernels.  The input is X||X (the same 7.2 M reads twice), so -- without an
-    oracle that large -- the result is pinned by what X alone gives through the partitioned path: the same key set
-    with every count doubled; hence every window passes the gate, the seeds are exactly the distinct first k-mers,
-    and the Bloom vector has no false negatives."""
+def test_beyond_2g_bases_position_chunks_and_direct_kernels():
+    """Maximum sizes: 2.16 G bases (> 2^31) exceed what one partition's 30-bit window positions address.  The pass cuts
+    the position space into 4 chunks that the count kernel takes as sources (fast path); with "chunks" = 1 the direct
+    global-table kernels do the same work ~20x slower.  The input is X||X (the same 7.2 M reads twice), so -- without
+    an oracle that large -- the result is pinned three ways: (i) by what X alone gives through the single-partition
+    path: the same key set with every count doubled, hence every window passes the gate and the seeds are exactly the
+    distinct first k-mers; (ii) chunked and direct runs, two independent device implementations, export identical
+    tables, Bloom words and seeds; (iii) the Bloom vector has no false negatives."""
+    import hashlib
+    from bench import bloom_sizing
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     R, k = 7_200_000, 31
     b, o = synth.reads(seed=9, total_reads=R, read_len=150)
     c = capi.Context(0)
+    c.set_option("chunks", 1)   # X alone: one partition (1.08 G positions: table-probe gate), no position chunks
     c.load_reads(b, o, k)
     c.count_short()
-    assert c.get_info("count_mode") == 2
+    assert c.get_info("count_mode") == 2 and c.get_info("chunks") == 1
     keys, counts = c.export_counts()
     c.close()
     bb = np.concatenate([b, b])
     oo = np.concatenate([o, o[1:] + o[-1]])
     assert bb.size > (1 << 31)
-    from bench import bloom_sizing
     m, H = bloom_sizing(int(bb.size), k)
-    c = capi.Context(0)
-    c.load_reads(bb, oo, k)
-    st = c.count_short()
-    assert c.get_info("count_mode") == 1
-    assert st["n_windows"] == 2 * R * 130 and st["n_solid"] == st["n_distinct"] == keys.size
-    k2, c2 = c.export_counts()
-    assert np.array_equal(keys, k2) and np.array_equal(counts * np.uint64(2), c2)
-    c.make_bloom(k, m, H)
-    bs = c.bloom_stats()
-    assert bs["n_passing"] == bs["n_windows_k"] == 2 * R * 120 and bs["n_seed_reads"] == 2 * R
-    seeds = c.export_seeds()
-    lut = np.zeros(256, np.uint64)
-    lut[ord("C")], lut[ord("G")], lut[ord("T")] = 1, 2, 3
-    starts = o[:-1].astype(np.int64)
-    first = np.zeros(R, np.uint64)
-    for i in range(k):
-        first = (first << np.uint64(2)) | lut[b[starts + i]]
-    assert np.array_equal(np.unique(first), seeds[:, 0])
-    samp = first[::97]
-    rc = np.zeros_like(samp)
-    for i in range(k):
-        rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
-    assert c.bloom_query(np.minimum(samp, rc)).all()
-    c.close()
+    digests = []
+    for direct in (False, True):
+        c = capi.Context(0)
+        if direct:
+            c.set_option("chunks", 1)
+        c.load_reads(bb, oo, k)
+        st = c.count_short()
+        assert (c.get_info("count_mode"), c.get_info("chunks")) == ((1, 1) if direct else (2, 4))
+        assert st["n_windows"] == 2 * R * 130 and st["n_solid"] == st["n_distinct"] == keys.size
+        k2, c2 = c.export_counts()
+        assert np.array_equal(keys, k2) and np.array_equal(counts * np.uint64(2), c2)
+        c.make_bloom(k, m, H)
+        bs = c.bloom_stats()
+        assert bs["n_passing"] == bs["n_windows_k"] == 2 * R * 120 and bs["n_seed_reads"] == 2 * R
+        seeds = c.export_seeds()
+        digests.append((sha(c.export_bloom()), sha(seeds)))
+        if not direct:
+            lut = np.zeros(256, np.uint64)
+            lut[ord("C")], lut[ord("G")], lut[ord("T")] = 1, 2, 3
+            starts = o[:-1].astype(np.int64)
+            first = np.zeros(R, np.uint64)
+            for i in range(k):
+                first = (first << np.uint64(2)) | lut[b[starts + i]]
+            assert np.array_equal(np.unique(first), seeds[:, 0])
+            samp = first[::97]
+            rc = np.zeros_like(samp)
+            for i in range(k):
+                rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
+            assert c.bloom_query(np.minimum(samp, rc)).all()
+        c.close()
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("R,L,k,ppm", [(2_000_000, 150, 31, 5000), (4000, 10_000, 63, 10_000), (300_000, 150, 21, 5000),
@@ -488,4 +502,33 @@ def test_second_level_partition(oracle, split, k):
     assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
     ebloom, _, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
     assert np.array_equal(c.export_bloom(), ebloom)
+    c.close()
+
+
+@pytest.mark.parametrize("chunks,k", [(2, 31), (4, 25), (8, 31), (4, 45)])
+def test_position_chunks_small(oracle, chunks, k):
+    """Inputs beyond 2^30 window positions are cut into 2, 4 or 8 position ranges that the count kernel takes as
+    sources; gate and Bloom stages then run range by range.  "chunks" forces that form on an input small enough
+    for the oracle (reads of mixed length, so that reads straddle the range boundaries)."""
+    rng = np.random.default_rng(chunks * 100 + k)
+    b0, o0 = synth.reads(seed=50 + chunks, total_reads=24000, read_len=150)
+    lens = rng.integers(k, 151, size=24000)
+    reads = [b0[int(o0[i]):int(o0[i]) + int(lens[i])] for i in range(24000)]
+    b = np.concatenate(reads)
+    o = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    c.set_option("chunks", chunks)
+    run_and_compare(c, oracle, (b, o), k, m, H)
+    assert c.get_info("chunks") == chunks and c.get_info("count_mode") == 2 and c.get_info("gate_mode") == 2
+    c.run_pass(k, m, H)
+    c.run_pass(k, m, H)
+    assert c.get_info("chunks") == chunks
+    keys, counts = c.export_counts()
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+    assert np.array_equal(c.export_bloom(), ebloom)
+    c.k = k
+    assert seeds_as_strings(c) == eseeds
     c.close()
