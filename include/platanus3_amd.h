@@ -75,10 +75,10 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 in LDS (bloom_mode reads back 3); 0 = global atomicOr per probe (bloom_mode 2)
  *   "tsk_log2"    log2 of the LDS k-mer-set slots per sub-bucket (<= 14; 2-word keys use 2 less)
  *   "chunks"      inputs beyond 2^30 window positions (~1.07 G bases) per GPU: 0 = auto -- the position space is cut into
- *                 2, 4 or 8 ranges of <= 2^30 positions (up to ~8.6 G bases) which the count kernel takes as sources;
+ *                 2, 4, 8 or 16 ranges of <= 2^30 positions (up to ~17 G bases) which the count kernel takes as sources;
  *                 gate and Bloom stages then run range by range; 1 = never (larger inputs then use the partitioned
  *                 count with the table-probe gate up to 2^31 positions, else the direct global-table kernels);
- *                 2 / 4 / 8 = force that many ranges (tests).  p3_get_info "chunks" reads back the number used.
+ *                 2 / 4 / 8 / 16 = force that many ranges (tests).  p3_get_info "chunks" reads back the number used.
  *   "count_split" 0 = auto: when a level-1 bucket would need an 8-way or finer sub-bucket split (large inputs, > ~3 M
  *                 reads of 150 bp), the position records are partitioned a second time (k_split) into 1024 cells per
  *                 group of 1024 >> x buckets and the groups are counted one after the other, each cell read once;

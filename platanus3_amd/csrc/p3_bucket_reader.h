@@ -14,13 +14,16 @@
 // Calls f(recs, active_mask) with batches of 4*(16/sizeof(REC)) records of bucket pb (bit i of the mask says
 // whether recs[i] is a real record).  ALL threads of the workgroup must call this (it
 // synchronises).  valid: LDS byte array of P3_VALID_CAP entries; sc2: two LDS u32 scratch words.
-// TAGGED: the table byte also carries (segment index / tag_div) in its top 3 bits and f gets the tag of each of the
-// four vectors as a third argument (k_part_count: the source rank of a re-partitioned cell's segment group).
+// TAGGED: the table entries are 16 bits wide (so the window is VCAP / 2 chunks): the high byte carries
+// (segment index / tag_div) and f gets the tag of each of the four vectors as a third argument (k_part_count: the
+// source -- rank or position chunk -- of a re-partitioned cell's segment group).
 template <typename REC, u32 VCAP = P3_VALID_CAP, bool TAGGED = false, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
                                                 const u32* __restrict__ ghist, u32 pb, uint8_t* valid, u32* sc2,
                                                 F f, u32 seg_begin = 0, u32 seg_count = P3_NWG, u32 tag_div = P3_NWG) {
   constexpr u32 RPV = 16 / sizeof(REC);  // records per 16-byte vector
+  constexpr u32 VC = TAGGED ? VCAP / 2 : VCAP;  // chunks per window
+  unsigned short* valid16 = reinterpret_cast<unsigned short*>(valid);
   constexpr u32 VPC = 16 / RPV;          // vectors per 16-record chunk
   // segment descriptor of thread t < seg_count (segments [seg_begin, seg_begin+seg_count) of row pb)
   u32 my_off = 0, my_n = 0;
@@ -36,10 +39,10 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
   const u32 nch = (sc2[1] - start) >> 4;       // chunks in the bucket
   const u32 my_c0 = (my_off - start) >> 4;     // first chunk of my segment
   const u32 my_nc = (my_n + 15u) >> 4;         // chunks of my segment
-  for (u32 wb = 0; wb < nch; wb += VCAP) {
-    const u32 wn = (nch - wb) < VCAP ? (nch - wb) : VCAP;
+  for (u32 wb = 0; wb < nch; wb += VC) {
+    const u32 wn = (nch - wb) < VC ? (nch - wb) : VC;
     // segments need not abut (estimated-capacity partitions leave gaps): unmarked chunks hold no records
-    for (u32 i = threadIdx.x; i < (wn + 3) / 4; i += blockDim.x) reinterpret_cast<u32*>(valid)[i] = 0;
+    for (u32 i = threadIdx.x; i < ((TAGGED ? 2 * wn : wn) + 3) / 4; i += blockDim.x) reinterpret_cast<u32*>(valid)[i] = 0;
     __syncthreads();
     if (threadIdx.x < seg_count) {
       // chunks [my_c0, my_c0+my_nc) intersected with [wb, wb+wn)
@@ -47,9 +50,9 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
       u32 hi = (my_c0 + my_nc) < (wb + wn) ? (my_c0 + my_nc) : (wb + wn);
       for (u32 c = lo; c < hi; c++) {
         const u32 left = my_n - ((c - my_c0) << 4);
-        u32 e = left < 16u ? left : 16u;
-        if constexpr (TAGGED) e |= (threadIdx.x / tag_div) << 5;
-        valid[c - wb] = (uint8_t)e;
+        const u32 e = left < 16u ? left : 16u;
+        if constexpr (TAGGED) valid16[c - wb] = (unsigned short)(e | ((threadIdx.x / tag_div) << 8));
+        else valid[c - wb] = (uint8_t)e;
       }
     }
     __syncthreads();
@@ -68,7 +71,8 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         const u32 ci = (j0 + u * B) / VPC;
-        nval[u] = (u32)valid[ci < VCAP ? ci : VCAP - 1];
+        if constexpr (TAGGED) nval[u] = (u32)valid16[ci < VC ? ci : VC - 1];
+        else nval[u] = (u32)valid[ci < VC ? ci : VC - 1];
       }
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
 #pragma unroll
       for (u32 u = 0; u < 4; u++) {
         const u32 nvalid = nval[u] & 31u;
-        tags[u] = nval[u] >> 5;
+        tags[u] = nval[u] >> 8;
         const u32 first = ((j0 + u * B) % VPC) * RPV;
         if constexpr (sizeof(REC) == 4) {
           recs[4 * u + 0] = v[u].x;

@@ -373,10 +373,10 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 144);
   const u64 tbase = (u64)sb * TS;  // this sub-bucket's window of tpairs (at most 7/8 TS entries are used)
   u32 cur_src = 0;
-  // A re-partitioned cell (xbits > 0) holds its 256 segments grouped by source rank; with at most 8 sources the
+  // A re-partitioned cell (xbits > 0) holds its 256 segments grouped by source; the
   // whole cell is read in ONE sweep and every record learns its source from the segment tag.  A queued record
   // keeps the tag in the top xbits bits of its low word (they hold the cell's constant xval otherwise).
-  const bool tagged = POS && xbits > 0 && n_src > 1 && n_src <= 8;
+  const bool tagged = POS && xbits > 0 && n_src > 1 && (1u << xbits) >= n_src;
   auto slow_insert = [&](REC item) {
     const u32 rem = (u32)item & rem_mask;
     const u32 item_src = tagged ? ((u32)item >> (32 - xbits)) : cur_src;

@@ -92,11 +92,11 @@ struct p3_ctx {
   u64 agg_padded = 0, agg_distinct_est = 0;
   // oversized single-GPU inputs: the position space is cut into `chunks` (2, 4 or 8) ranges of <= 2^30 positions that
   // the count stage treats as sources; gate and Bloom stages then run chunk by chunk
-  u32 chunks = 1;
+  u32 chunks = 1;  // 2, 4, 8 or 16 when in use
   bool chunk_acc = false;    // do_bloom_t: later chunk (keep the Bloom vector, OR into it), no seeds yet
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
-  u64 chunk_w0[9] = {0};
+  u64 chunk_w0[17] = {0};
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
   int split_opt = 0;        // 0 = auto, 1 = never, 2..6 = force split_xbits = value - 1
@@ -812,7 +812,7 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
 
 // ---- oversized single-GPU inputs: position chunks -----------------------------------------------------------------
 // Records address a window by a 30-bit position, so one partition covers at most 2^30 positions.  A larger input
-// (up to 8 x 2^30 positions) is cut into 2, 4 or 8 word ranges; each range is partitioned on its own (positions
+// (up to 16 x 2^30 positions) is cut into 2, 4, 8 or 16 word ranges; each range is partitioned on its own (positions
 // relative to the range), the count kernel takes the ranges as SOURCES -- exactly as it takes the ranks of the
 // multi-rank protocol: first instances are credited per source, so the non-solid positions come back per range --
 // and the gate and Bloom stages then run range by range on narrowed views of the stream buffers.
@@ -857,7 +857,7 @@ u32 chunks_for(const p3_ctx* c) {  // 0 = the chunked form does not apply
   if (c->chunk_opt >= 2) return (pos / (u32)c->chunk_opt <= (1ull << 30)) ? (u32)c->chunk_opt : 0;
   if (pos <= (1ull << 30)) return 0;
   u32 n = 2;
-  while (n < 8 && (pos + n - 1) / n > (1ull << 30)) n <<= 1;
+  while (n < 16 && (pos + n - 1) / n > (1ull << 30)) n <<= 1;
   return ((pos + n - 1) / n <= (1ull << 30)) ? n : 0;
 }
 
@@ -881,7 +881,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   if ((rc = ensure(c, c->rx_segoff_buf, (size_t)C * desc))) return rc;
   if ((rc = ensure(c, c->rx_roff, 8 * (P3_MAX_RANKS + 1)))) return rc;
   if ((rc = ensure(c, c->sroff_d, 8 * (P3_MAX_RANKS + 1)))) return rc;
-  u64 roff[P3_MAX_RANKS + 1] = {0}, sroff[P3_MAX_RANKS + 1] = {0}, windows[8] = {0};
+  u64 roff[P3_MAX_RANKS + 1] = {0}, sroff[P3_MAX_RANKS + 1] = {0}, windows[16] = {0};
   u64 total = 0;
   {
     ChunkView view(c);
@@ -1432,7 +1432,8 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
   } else if (n == "chunks") {
-    if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return fail(c, P3_EBADARG, "chunks must be 0, 1, 2, 4 or 8");
+    if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16))
+      return fail(c, P3_EBADARG, "chunks must be 0, 1, 2, 4, 8 or 16");
     c->chunk_opt = (int)value;
   } else if (n == "count_split") {
     if (value < 0 || value > 6) return fail(c, P3_EBADARG, "count_split must be in [0,6]");

@@ -505,7 +505,7 @@ def test_second_level_partition(oracle, split, k):
     c.close()
 
 
-@pytest.mark.parametrize("chunks,k", [(2, 31), (4, 25), (8, 31), (4, 45)])
+@pytest.mark.parametrize("chunks,k", [(2, 31), (4, 25), (8, 31), (4, 45), (16, 31), (16, 63)])
 def test_position_chunks_small(oracle, chunks, k):
     """Inputs beyond 2^30 window positions are cut into 2, 4 or 8 position ranges that the count kernel takes as
     sources; gate and Bloom stages then run range by range.  "chunks" forces that form on an input small enough

@@ -8,7 +8,9 @@ from bench import bloom_sizing
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
-b, o = synth.reads(seed=11, total_reads=R, read_len=150)
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+ppm = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
+b, o = synth.reads(seed=11, total_reads=R, read_len=L, sub_rate_ppm=ppm)
 m, H = bloom_sizing(int(b.size), k)
 print("%d reads, %.2f G bases, m=%d" % (R, b.size / 1e9, m), flush=True)
 h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
