@@ -669,7 +669,8 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
                                                                  u32 k, ModM mm, u32 H, u32 slice_log2,
                                                                  const u32* __restrict__ seg_off, u32* __restrict__ out,
                                                                  const u64* __restrict__ totals, u64 cap,
-                                                                 u64* __restrict__ cap_flag, EstSeg est) {
+                                                                 u64* __restrict__ cap_flag, EstSeg est, u32 slice_base,
+                                                                 u32 slice_cnt) {
   if (!est.segcap && totals[1] > cap) {  // exact mode: the padded total must fit the buffer
     if (blockIdx.x == 0 && threadIdx.x == 0) *cap_flag = 1;
     return;
@@ -705,9 +706,14 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
         rec[t] = 0;
         bkt[t] = 0;
         if (active && done + (u32)t < H) {
-          rec[t] = (u32)pr.r & smask;
-          bkt[t] = (u32)(pr.r >> slice_log2);
-          pend |= 1u << t;
+          // a vector of more than 1024 slices is built in several sweeps: this one keeps slices
+          // [slice_base, slice_base + slice_cnt) and merely steps over the other probes
+          const u32 sid = (u32)(pr.r >> slice_log2) - slice_base;
+          if (sid < slice_cnt) {
+            rec[t] = (u32)pr.r & smask;
+            bkt[t] = sid;
+            pend |= 1u << t;
+          }
           probe_step(pr, mm);
         }
       }
@@ -722,7 +728,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
 __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
                                                        u32* __restrict__ bloom, const u64* __restrict__ cap_flag,
-                                                       u32 accumulate) {
+                                                       u32 accumulate, u32 slice_base) {
   if (*cap_flag) return;  // the probe partition did not fit: the host repeats the stage
   extern __shared__ __align__(16) u32 lds[];
   const u32 words = 1u << (slice_log2 - 5);
@@ -738,7 +744,7 @@ __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ p
       if (act & (1u << i)) atomicOr(&bm[r[i] >> 5], 1u << (r[i] & 31));
   });
   __syncthreads();
-  const u64 w0 = (u64)s * words;
+  const u64 w0 = (u64)(slice_base + s) * words;
   for (u32 i = threadIdx.x; i < words; i += blockDim.x)
     if (w0 + i < n_u32) bloom[w0 + i] = accumulate ? (bloom[w0 + i] | bm[i]) : bm[i];  // accumulate: later position chunks
 }

@@ -1079,37 +1079,44 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       c->ksbits_epoch = c->reads_epoch;
       c->ksbits_k = k;
       if (!c->spec) c->n_distinct_k = h[0];
-      // slices of 2^slice_log2 bits, at most 1024 of them and at most 128 KiB of LDS each
+      // slices of 2^slice_log2 bits (<= 2^20: 128 KiB of LDS), 1024 per sweep; a vector of more than 2^30 bits takes
+      // several sweeps over the distinct keys (estimated-capacity form only), each keeping the probes of its slices
       u32 slice_log2 = 10;
-      while (((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
+      while (slice_log2 < 20 && ((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
+      const u64 ns_total = (m + ((1ull << slice_log2) - 1)) >> slice_log2;
+      const u32 sweeps = (u32)((ns_total + P3_NB - 1) / P3_NB);
       const u64 n_pos = c->n_distinct_k * (u64)H;  // spec: last pass's count; the scatter checks the real one
-      const bool sliced = c->bloom_slices_opt && slice_log2 <= 20 && n_pos + 16ull * P3_NWG * P3_NB < (1ull << 31);
+      const bool sliced = c->bloom_slices_opt && (sweeps == 1 || (est && sweeps <= 64)) &&
+                          n_pos / sweeps + n_pos / 8 + 16ull * P3_NWG * P3_NB < (1ull << 31);
       if (sliced) {
-        const u32 ns = (u32)((m + ((1ull << slice_log2) - 1)) >> slice_log2);
-        if (est) {
-          // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
-          const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
-          const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
-          const u32 segcap_p = segcap_for((double)per_keys * H / ns);
-          if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
-          if ((rc = fixed_segoff(c, segcap_p))) return rc;
-          LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                     (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                     (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}));
-        } else {
-          if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
-          const u64 cap_records = c->ppart.bytes / 4;
-          LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
-                 mm, H, slice_log2, (u32*)c->ghist.p);
-          if ((rc = do_scan(c, st + 12))) return rc;
-          LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                     (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                     (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}));
-        }
         const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
-        LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
-                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
-                   (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u));
+        for (u32 sw = 0; sw < sweeps; sw++) {
+          const u32 sbase = sw * P3_NB;
+          const u32 ns = (u32)(ns_total - sbase < P3_NB ? ns_total - sbase : P3_NB);
+          if (est) {
+            // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
+            const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
+            const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
+            const u32 segcap_p = segcap_for((double)per_keys * H / (double)ns_total);
+            if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
+            if ((rc = fixed_segoff(c, segcap_p))) return rc;
+            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                       (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                       (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), sbase, ns);
+          } else {
+            if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
+            const u64 cap_records = c->ppart.bytes / 4;
+            LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
+                   mm, H, slice_log2, (u32*)c->ghist.p);
+            if ((rc = do_scan(c, st + 12))) return rc;
+            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                       (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                       (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
+          }
+          LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
+                     (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
+                     (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase);
+        }
         c->bloom_mode = 3;
       } else {
         LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H,

@@ -19,6 +19,7 @@ for mode in ("chunked", "direct"):
     c = capi.Context(0)
     if mode == "direct":
         c.set_option("chunks", 1)
+        c.set_option("bloom_slices", 0)   # and global atomicOr per probe instead of the (multi-sweep) slices
     c.load_reads(b, o, k)
     c.run_pass(k, m, H)
     t0 = time.perf_counter()
