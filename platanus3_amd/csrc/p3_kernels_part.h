@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u64* __restrict__ gstats, u64* __restrict__ tpairs,
                                                      u32* __restrict__ singles,
                                                      u64* __restrict__ sing_cursor, u32 dbg, u32 mode,
-                                                     const u64* __restrict__ sroff) {
+                                                     const u64* __restrict__ sroff, u64 out_cap) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
   // sroff: where each source's list of single-instance positions starts in `singles` (null: same as roff, the
   // record offsets of the sources -- the lists then sit at the start of the sources' own regions)
@@ -481,6 +481,12 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   }
   __syncthreads();
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
+  // out_keys / out_counts hold out_cap entries (an estimate when the input is huge): never write past them, tell
+  // the host instead (gstats[31]), which repeats the stage with larger outputs
+  if (out_keys && base + s_ndist > out_cap) {
+    if (threadIdx.x == 0) gstats[31] = 1;
+    return;
+  }
   if constexpr (POS) {
     if (mode & P3_K2_AGG_OUT) {
       // one record per distinct key, in place over this sub-bucket's first-instance pairs; k_agg_compact

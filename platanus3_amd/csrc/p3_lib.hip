@@ -97,6 +97,7 @@ struct p3_ctx {
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
   u64 chunk_w0[17] = {0};
+  u64 distinct_cap = 0;      // entries of the count table outputs when sized from an estimate (position chunks)
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
   int split_opt = 0;        // 0 = auto, 1 = never, 2..6 = force split_xbits = value - 1
@@ -288,6 +289,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->reads_epoch++;
   c->hint_valid = false;
   c->est_ok = true;
+  c->distinct_cap = 0;
   c->host_windows = 0;
   c->pass_hint = 0;
   return P3_OK;
@@ -518,14 +520,14 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
-               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u), (const u64*)nullptr);
+               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u), (const u64*)nullptr, maxd);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u, (const u64*)nullptr);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u, (const u64*)nullptr, maxd);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -567,14 +569,18 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const u32 groups = 1u << xg, rows = rows_total >> xg;
   const u32 first_pb = mr ? c->rank * rows_total : 0u;
   const u32 nsb = P3_NB << sbits;
+  // worst case one entry per record; position chunks (tens of GB of records) size the table from an estimate of the
+  // distinct keys instead -- the count kernel refuses to write past it and the stage is then repeated larger
   u64 maxd = c->rx_records + 1;
+  if (chunked && c->distinct_cap && c->distinct_cap < maxd) maxd = c->distinct_cap;
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
-  if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
+  if ((rc = ensure(c, c->ccounts, maxd * 4))) return rc;
   if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
   if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 31, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
@@ -597,7 +603,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
                (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
                (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u),
-               (const u64*)(chunked ? c->sroff_d.p : nullptr));
+               (const u64*)(chunked ? c->sroff_d.p : nullptr), maxd);
   }
   HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
@@ -614,6 +620,10 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
     c->est_ok = false;
     c->est_fallbacks++;
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+  }
+  if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
+    c->distinct_cap = maxd * 2;
+    return count_split(c, xg, sbits, overflowed, max_solid_sb);
   }
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
@@ -740,7 +750,7 @@ int agg_local(p3_ctx* c) {
   LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
              (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
              sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
-             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT, (const u64*)nullptr);
+             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT, (const u64*)nullptr, (u64)0);
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
@@ -756,7 +766,7 @@ int agg_local(p3_ctx* c) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
                (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
                (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
-               (u32)P3_K2_AGG_OUT, (const u64*)nullptr);
+               (u32)P3_K2_AGG_OUT, (const u64*)nullptr, (u64)0);
     HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h[3]) break;
@@ -916,6 +926,9 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   c->rx_records = total;
   c->rx_weighted = false;
   c->part_pos = true;
+  // count table outputs: a quarter of the records to start with (30x coverage gives 1/7, 1 % errors on long reads
+  // 1/4.5); the count kernel reports when that is too small and the size doubles
+  if (!c->distinct_cap) c->distinct_cap = total / 4 + (1ull << 20);
   // split bits: cells of <= ~96 Ki records (uncapped version of initial_sbits), at least log2(C) so that the split
   // kernel's item list (rows x sources) stays within 1024
   u32 xg = 0;
@@ -1438,6 +1451,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "distinct_cap") {  // tests: entries of the estimate-sized count table outputs (position chunks)
+    if (value < 0) return fail(c, P3_EBADARG, "distinct_cap must be >= 0");
+    c->distinct_cap = (u64)value;
   } else if (n == "chunks") {
     if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16))
       return fail(c, P3_EBADARG, "chunks must be 0, 1, 2, 4, 8 or 16");
