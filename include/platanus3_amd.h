@@ -83,6 +83,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 reads of 150 bp), the position records are partitioned a second time (k_split) into 1024 cells per
  *                 group of 1024 >> x buckets and the groups are counted one after the other, each cell read once;
  *                 1 = never; x+1 (2..6) = force x split bits (tests).  p3_get_info "split_xbits" reads back x.
+ *   "kmer_split"  0 = auto: the same second-level partition for the passing k-mer records of the Bloom stage, taken from
+ *                 an 8-way set split on; x+1 (2..11) = force x split bits (tests); "count_split" = 1 switches it off
+ *                 as well.  p3_get_info "ksplit_xbits" reads back x.
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 3x -- fewer bytes to

@@ -297,10 +297,16 @@ __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pai
 // every cell is single-source (the count kernel's source tags rely on that) and the work is balanced.
 // Output: standard [cell][256] segments of estimated capacity (est.segcap, counts to est.ghist_out, *est.ovf on
 // overflow).  in_segoff / in_ghist: [n_src][desc_rows][256] descriptors; the rows used are first_row .. first_row+rows.
-__global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict__ in, const u32* __restrict__ in_segoff,
+// KIND 0: 21-mer position records (u64): the cell bits are the top xbits bits of the record's low word.
+// KIND 1 / 2: canonical k-mer records of the Bloom stage (u64 / Rec16): the cell bits are the xbits bits below the
+// bucket bits of the k-mer's bucket hash (kfold * C1), i.e. the bits a sub-bucket split of the dedup stage would use.
+template <typename REC, int KIND>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
                                                           const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
                                                           u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
-                                                          u64* __restrict__ out, EstSeg est) {
+                                                          REC* __restrict__ out, EstSeg est) {
+  constexpr u32 RPV = 16 / sizeof(REC);  // records per 16-byte vector
+  constexpr int N = 2 * (int)RPV;        // records per lane and step (two vectors)
   extern __shared__ __align__(16) u32 lds[];
   const StageLds stg = stage_layout(lds);
   u32* item_off = lds + P3_STAGE_WORDS;  // [rows * n_src] first record of the item (relative to the source's data)
@@ -318,25 +324,26 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
   }
   if (threadIdx.x == 0) *s_maxsteps = 0;
   __syncthreads();
-  const u64* data = in + roff[src] - in_segoff[(u64)src * desc_rows * P3_NWG];
+  const REC* data = in + roff[src] - in_segoff[(u64)src * desc_rows * P3_NWG];
   // 2^xbits lanes per group: (1024 >> xbits) groups x 2^xbits cells each = all 1024 stager rows in play per round
   const u32 GL = 1u << xbits, ngroups = P3_PART_THREADS >> xbits;
   const u32 grp = threadIdx.x >> xbits, gl = threadIdx.x & (GL - 1);
   // steps (of 2 GL vectors: two per lane) this group needs for its items grp, grp + ngroups, ...
   u32 my_steps = 0;
-  for (u32 i = grp; i < n_items; i += ngroups) my_steps += ((item_cnt[i] + 1) / 2 + 2 * GL - 1) / (2 * GL);
+  for (u32 i = grp; i < n_items; i += ngroups) my_steps += ((item_cnt[i] + RPV - 1) / RPV + 2 * GL - 1) / (2 * GL);
   if (gl == 0) atomicMax(s_maxsteps, my_steps);
   __syncthreads();
   const u32 max_steps = *s_maxsteps;
   u32 it = grp, vi = 0;  // current item and first vector of the next step
   u32 cnt = it < n_items ? item_cnt[it] : 0, off = it < n_items ? item_off[it] : 0;
   u32 step = 0;
+  const u32 cmask = (1u << xbits) - 1u;
   // software-pipelined (stage_run): the loads of step s+1 are issued between the two barriers of step s, so their
   // latency hides behind the flush instead of stalling every round
-  stage_run<u64, 4>(stg, out, est, [&](u64 (&rec)[4], u32 (&bkt)[4], u32& pend) -> bool {
+  stage_run<REC, N>(stg, out, est, [&](REC (&rec)[N], u32 (&bkt)[N], u32& pend) -> bool {
     if (step >= max_steps) return false;
     step++;
-    while (it < n_items && vi * 2 >= cnt) {  // item exhausted (or empty): next one of this group
+    while (it < n_items && vi * RPV >= cnt) {  // item exhausted (or empty): next one of this group
       it += ngroups;
       vi = 0;
       if (it < n_items) {
@@ -346,10 +353,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
     }
     pend = 0;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      rec[t] = 0;
-      bkt[t] = 0;
-    }
+    for (int t = 0; t < N; t++) bkt[t] = 0;
     if (it < n_items) {
       const uint4* vecs = reinterpret_cast<const uint4*>(data + off);
       const u32 rbase = (it / n_src) << xbits;
@@ -357,17 +361,30 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const u64* __restrict
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const u32 v = vi + gl + GL * h;
-        q[h] = vecs[v * 2 < cnt ? v : 0u];  // branch-free: a lane past the end re-reads vector 0 and masks it out
+        q[h] = vecs[v * RPV < cnt ? v : 0u];  // branch-free: a lane past the end re-reads vector 0 and masks it out
       }
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const u32 v = vi + gl + GL * h;
-        rec[2 * h] = ((u64)q[h].y << 32) | q[h].x;
-        rec[2 * h + 1] = ((u64)q[h].w << 32) | q[h].z;
-        bkt[2 * h] = rbase | (q[h].x >> (32 - xbits));
-        bkt[2 * h + 1] = rbase | (q[h].z >> (32 - xbits));
-        if (v * 2 < cnt) pend |= 1u << (2 * h);
-        if (v * 2 + 1 < cnt) pend |= 2u << (2 * h);
+        if constexpr (KIND == 2) {
+          rec[h].lo = ((u64)q[h].y << 32) | q[h].x;
+          rec[h].hi = ((u64)q[h].w << 32) | q[h].z;
+          bkt[h] = rbase | (((kfold<2>(rec[h].lo, rec[h].hi) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask);
+          if (v < cnt) pend |= 1u << h;
+        } else {
+          const u64 r0 = ((u64)q[h].y << 32) | q[h].x, r1 = ((u64)q[h].w << 32) | q[h].z;
+          rec[2 * h] = r0;
+          rec[2 * h + 1] = r1;
+          if constexpr (KIND == 0) {
+            bkt[2 * h] = rbase | (q[h].x >> (32 - xbits));
+            bkt[2 * h + 1] = rbase | (q[h].z >> (32 - xbits));
+          } else {
+            bkt[2 * h] = rbase | (((kfold<1>(r0, 0) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask);
+            bkt[2 * h + 1] = rbase | (((kfold<1>(r1, 0) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask);
+          }
+          if (v * 2 < cnt) pend |= 1u << (2 * h);
+          if (v * 2 + 1 < cnt) pend |= 2u << (2 * h);
+        }
       }
       vi += 2 * GL;
     }

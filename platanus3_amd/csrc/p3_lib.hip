@@ -97,6 +97,9 @@ struct p3_ctx {
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
   u64 chunk_w0[17] = {0};
+  int ksplit_opt = 0;         // 0 = auto, x+1 (2..11) = force x split bits for the k-mer records (tests)
+  u32 kxg = 0, hint_kxg = 0;  // split bits of the k-mer records' second-level partition (0 = not used)
+  DevBuf klpart, zero8;
   u64 distinct_cap = 0;      // entries of the count table outputs when sized from an estimate (position chunks)
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
@@ -596,7 +599,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
   for (u32 g = 0; g < groups; g++) {
-    LAUNCH_LDS(c, "k_split", k_split, P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
+    LAUNCH_LDS(c, "k_split", (k_split<u64, 0>), P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
                (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, mr ? rows_total : (u32)P3_NB, g * rows, rows, xbits,
                (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
@@ -1062,33 +1065,77 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
     const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
                        16 * 192 * sizeof(REC);
-    u32 sbits = 0;
+    u32 sbits = 0, kxg = 0;
+    // plain form: one workgroup per sub-bucket, each reading the whole bucket (2^sbits reads of every record);
+    // split form (kxg > 0), for large inputs: the k-mer records are partitioned a second time (k_split) into
+    // 1024 cells per group of 1024 >> kxg buckets and every cell is read once
+    const double krecords = mean_k * (double)P3_NB * active_wgs(c->n_words);  // estimate of the passing k-mers
+    auto dedup_once = [&](u32 sb, u32 xg) -> int {
+      HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
+      if (!xg) {
+        LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sb, 1024, lds, (const REC*)c->kpart.p,
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst,
+                   (u32)c->dbg_opt);
+        return P3_OK;
+      }
+      int r2;
+      const u32 groups = 1u << xg, rows = P3_NB >> xg;
+      const u32 segcap2 = segcap_for(krecords / ((double)groups * P3_NB * P3_NWG));
+      if ((r2 = ensure(c, c->klpart, (u64)P3_NB * P3_NWG * segcap2 * sizeof(REC)))) return r2;
+      if ((r2 = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return r2;
+      if ((r2 = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return r2;
+      if ((r2 = ensure(c, c->zero8, 8 * (P3_MAX_RANKS + 1)))) return r2;
+      HIPCHK(c, hipMemsetAsync(c->zero8.p, 0, 8 * (P3_MAX_RANKS + 1), c->stream));
+      LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap2);
+      const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
+      for (u32 g = 0; g < groups; g++) {
+        LAUNCH_LDS(c, "k_split", (k_split<REC, (NW == 1 ? 1 : 2)>), P3_NWG, P3_PART_THREADS, lds_split, (const REC*)c->kpart.p,
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->zero8.p, 1u, (u32)P3_NB, g * rows, rows, xg,
+                   (REC*)c->klpart.p, (EstSeg{segcap2, (u32*)c->ghist2.p, st + 25}));
+        LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB, 1024, lds, (const REC*)c->klpart.p,
+                   (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
+      }
+      return P3_OK;
+    };
     if (c->spec) {
       sbits = c->hint_ksbits;  // no readback: overflow is checked at the end of the pass
-      HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
-      LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sbits, 1024, lds, (const REC*)c->kpart.p,
-                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, dst,
-                 (u32)c->dbg_opt);
+      kxg = c->hint_kxg;
+      if ((rc = dedup_once(sbits, kxg))) return rc;
     } else {
       while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
       // the split that worked for the previous pass over the same reads and k is the best first guess
-      if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k && c->ksbits > sbits && c->ksbits <= 5) sbits = c->ksbits;
-      for (;; sbits++) {
-        if (sbits > 5) {
+      if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k) {
+        if (c->kxg) {
+          kxg = c->kxg;
+          sbits = 0;
+        } else if (c->ksbits > sbits && c->ksbits <= 5) {
+          sbits = c->ksbits;
+        }
+      }
+      if (c->ksplit_opt >= 2) {  // tests: force the split form
+        kxg = (u32)c->ksplit_opt - 1;
+        sbits = 0;
+      }
+      for (;;) {
+        if (!kxg && sbits >= 3 && est && c->split_opt != 1) {  // an 8-way split or finer: partition the k-mers once more
+          kxg = sbits;
+          sbits = 0;
+        }
+        if ((!kxg && sbits > 5) || kxg > 10) {
           use_dedup = false;  // every split overflowed: fall back to the direct form below
           break;
         }
-        HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
-        LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sbits, 1024, lds, (const REC*)c->kpart.p,
-                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sbits, ts_log2, (u64*)c->dkeys.p, dst,
-                   (u32)c->dbg_opt);
+        if ((rc = dedup_once(sbits, kxg))) return rc;
         HIPCHK(c, hipMemcpyAsync(h, dst, 5 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (h[3] == 0) break;
+        if (kxg) kxg++;
+        else sbits++;
       }
     }
     if (use_dedup) {
       c->ksbits = sbits;
+      c->kxg = kxg;
       c->ksbits_epoch = c->reads_epoch;
       c->ksbits_k = k;
       if (!c->spec) c->n_distinct_k = h[0];
@@ -1412,7 +1459,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
-                    &c->ghist2, &c->part8c, &c->sroff_d};
+                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1451,6 +1498,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "kmer_split") {
+    if (value < 0 || value > 11) return fail(c, P3_EBADARG, "kmer_split must be in [0,11]");
+    c->ksplit_opt = (int)value;
   } else if (n == "distinct_cap") {  // tests: entries of the estimate-sized count table outputs (position chunks)
     if (value < 0) return fail(c, P3_EBADARG, "distinct_cap must be >= 0");
     c->distinct_cap = (u64)value;
@@ -1481,6 +1531,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "gate_mode") *value = c->gate_mode;
   else if (n == "nonsolid_windows") *value = (int64_t)c->sing_count[0];
   else if (n == "ksbits") *value = c->ksbits;
+  else if (n == "ksplit_xbits") *value = c->kxg;
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
   else if (n == "rs_log2") *value = c->rs_log2;
@@ -2082,6 +2133,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     c->hint_sbits = c->sbits;
     c->hint_xbits = c->split_xbits;
     c->hint_ksbits = c->ksbits;
+    c->hint_kxg = c->kxg;
     c->hint_nsing = c->sing_count[0];
     c->hint_k = k;
     c->hint_m = m_bits;

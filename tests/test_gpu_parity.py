@@ -167,7 +167,8 @@ def test_count_paths(oracle, mode, ts_log2, expect_mode, gate):
                                                     (63, -2, 13, 2)])
 def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
     """direct (probe per window) vs dedup (probe per distinct k-mer) Bloom build, including LDS-set overflow
-    -> re-split (tsk_log2=7) and overflow at every split -> direct fallback (tsk_log2=4)."""
+    -> re-split (tsk_log2=7, 8: sub-bucket splits, then the second-level partition of the k-mer records) and, with
+    that partition switched off, overflow at every split -> direct fallback (tsk_log2=4)."""
     c = capi.Context(0)
     try:
         if mode < 0:  # dedup, but global atomicOr per probe instead of LDS slices
@@ -175,12 +176,14 @@ def test_bloom_paths(oracle, k, mode, tsk, expect_mode):
             mode = -mode
         c.set_option("bloom_mode", mode)
         c.set_option("tsk_log2", tsk)
+        if tsk == 4:
+            c.set_option("count_split", 1)   # no second-level partitions: 16-slot sets overflow at every split
         b, o = synth.reads(seed=23, total_reads=60000, read_len=150)
         m, H = oracle.estimate_bloom(int(b.size), k)
         run_and_compare(c, oracle, (b, o), k, m, H)
         assert c.get_info("bloom_mode") == expect_mode
         if tsk in (7, 8):
-            assert c.get_info("ksbits") > 0
+            assert c.get_info("ksbits") > 0 or c.get_info("ksplit_xbits") > 0
     finally:
         c.close()
 
@@ -532,6 +535,29 @@ def test_position_chunks_small(oracle, chunks, k):
     ekeys, ecounts = oracle.count_short((b, o), min_len=k)
     ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
     assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+    assert np.array_equal(c.export_bloom(), ebloom)
+    c.k = k
+    assert seeds_as_strings(c) == eseeds
+    c.close()
+
+
+@pytest.mark.parametrize("split,k", [(2, 31), (4, 27), (6, 41), (3, 63)])
+def test_kmer_second_level_partition(oracle, split, k):
+    """kmer_split = x+1 forces the large-input form of the dedup stage: the passing k-mer records (8 or 16 bytes) are
+    partitioned a second time (k_split) into 1024 cells per group of 1024 >> x buckets and every cell is deduplicated
+    by one workgroup, instead of 2^s workgroups re-reading every bucket."""
+    n, L = (20000, 150) if k < 60 else (400, 5000)
+    b, o = synth.reads(seed=70 + split, total_reads=n, read_len=L, sub_rate_ppm=5000 if k < 60 else 10000)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    c.set_option("kmer_split", split)
+    run_and_compare(c, oracle, (b, o), k, m, H)
+    assert c.get_info("ksplit_xbits") == split - 1 and c.get_info("bloom_mode") == 3
+    c.run_pass(k, m, H)   # careful pass, then the speculative one with the remembered split
+    c.run_pass(k, m, H)
+    assert c.get_info("ksplit_xbits") == split - 1
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
     assert np.array_equal(c.export_bloom(), ebloom)
     c.k = k
     assert seeds_as_strings(c) == eseeds
