@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restr
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
 }
 
-template <int NW>
+template <int NW, bool MULTI>  // MULTI: one of several sweeps over a vector of more than 1024 slices
 // totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
 // raises *cap_flag and writes nothing (the host re-runs with a larger buffer).
 __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
@@ -708,8 +708,8 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
         if (active && done + (u32)t < H) {
           // a vector of more than 1024 slices is built in several sweeps: this one keeps slices
           // [slice_base, slice_base + slice_cnt) and merely steps over the other probes
-          const u32 sid = (u32)(pr.r >> slice_log2) - slice_base;
-          if (sid < slice_cnt) {
+          const u32 sid = (u32)(pr.r >> slice_log2) - (MULTI ? slice_base : 0u);
+          if (!MULTI || sid < slice_cnt) {
             rec[t] = (u32)pr.r & smask;
             bkt[t] = sid;
             pend |= 1u << t;

@@ -296,7 +296,9 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __r
 //   sing_cursor[s] (zeroed by the host) = entries emitted for source s; list s starts at singles[roff[s]].
 #define P3_VCAP_POS 4096u
 #define P3_WQ_CAP_POS 192u
-template <bool POS>
+// TAGGED (POS only): a re-partitioned multi-source cell is read in one sweep with per-segment source tags; it is a
+// template parameter so that the single-source kernel does not carry that code.
+template <bool POS, bool TAGGED = false>
 __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off,
                                                      const u32* __restrict__ ghist, const u64* __restrict__ roff,
@@ -305,12 +307,11 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
                                                      u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                      u64* __restrict__ gstats, u64* __restrict__ tpairs,
                                                      u32* __restrict__ singles,
-                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode,
-                                                     const u64* __restrict__ sroff, u64 out_cap) {
+                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
-  // sroff: where each source's list of single-instance positions starts in `singles` (null: same as roff, the
-  // record offsets of the sources -- the lists then sit at the start of the sources' own regions)
-  if (!sroff) sroff = roff;
+  // Two rarely used inputs ride in arrays the kernel has anyway (more kernel arguments cost the hot loop registers):
+  // gstats[30] = entries that out_keys / out_counts hold; sing_cursor[P3_MAX_RANKS + s] = where source s's list of
+  // single-instance positions starts in `singles`.
   // mode & P3_K2_WEIGHTED (POS only): the records are locally pre-aggregated -- bit 63 set = "this key occurred
   // (bits 62..32) times at the sender", clear = one instance at window position (bits 62..32).
   // mode & P3_K2_AGG_OUT (POS only): emit such records instead of the table (the sender side of the above).
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   // A re-partitioned cell (xbits > 0) holds its 256 segments grouped by source; the
   // whole cell is read in ONE sweep and every record learns its source from the segment tag.  A queued record
   // keeps the tag in the top xbits bits of its low word (they hold the cell's constant xval otherwise).
-  const bool tagged = POS && xbits > 0 && n_src > 1 && (1u << xbits) >= n_src;
+  const bool tagged = POS && xbits > 0 && n_src > 1 && (1u << xbits) >= n_src;  // (TAGGED is then set as well)
   auto slow_insert = [&](REC item) {
     const u32 rem = (u32)item & rem_mask;
     const u32 item_src = tagged ? ((u32)item >> (32 - xbits)) : cur_src;
@@ -483,7 +484,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
   // out_keys / out_counts hold out_cap entries (an estimate when the input is huge): never write past them, tell
   // the host instead (gstats[31]), which repeats the stage with larger outputs
-  if (out_keys && base + s_ndist > out_cap) {
+  const u64* sroff = sing_cursor + P3_MAX_RANKS;
+  if (out_keys && base + s_ndist > gstats[30]) {
     if (threadIdx.x == 0) gstats[31] = 1;
     return;
   }

@@ -100,6 +100,7 @@ struct p3_ctx {
   int ksplit_opt = 0;         // 0 = auto, x+1 (2..11) = force x split bits for the k-mer records (tests)
   u32 kxg = 0, hint_kxg = 0;  // split bits of the k-mer records' second-level partition (0 = not used)
   DevBuf klpart, zero8;
+  u64 k2ext_h[2] = {0, 0};
   u64 distinct_cap = 0;      // entries of the count table outputs when sized from an estimate (position chunks)
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
@@ -355,7 +356,9 @@ bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG 
 
 // Estimated-capacity segments (single rank): capacity = mean + 6 sigma + slack records, multiple of 16
 u32 segcap_for(double mean) {
-  const double c = mean + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) + 32.0;
+  // (the constant slack matters for tiny means only; every 16 records of capacity is 16 records of gap the readers
+  // step over, ~2.4 % of a 672-record segment)
+  const double c = mean + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) + (mean >= 256.0 ? 16.0 : 32.0);
   return ((u32)c + 15u) & ~15u;
 }
 
@@ -469,6 +472,19 @@ int repartition_rx(p3_ctx* c) {
 
 int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb);
 
+// the count kernel's two rarely used inputs (see k_part_count): dstats[30] = entries its table outputs hold,
+// sing_cursor[P3_MAX_RANKS + s] = start of source s's list in `singles` (copied from the device table `sroff`, n of them)
+int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
+  int rc;
+  if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
+  c->k2ext_h[0] = out_cap;
+  HIPCHK(c, hipMemcpyAsync((u64*)c->dstats.p + 30, c->k2ext_h, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync((u64*)c->sing_cursor.p + P3_MAX_RANKS, 0, 8 * P3_MAX_RANKS, c->stream));
+  if (sroff && n)
+    HIPCHK(c, hipMemcpyAsync((u64*)c->sing_cursor.p + P3_MAX_RANKS, sroff, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+  return P3_OK;
+}
+
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
@@ -510,27 +526,36 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
   if ((rc = ensure(c, c->ccounts, maxd * 8))) return rc;
   if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
+  if ((rc = set_k2ext(c, maxd, c->n_ranks > 1 ? c->rx_roff.p : nullptr, c->n_ranks))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if (c->part_pos) {
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;  // (src|slot|pos) per first instance
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
-    if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
+    if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
     HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
-    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)kpart,
-               (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
-               c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
-               (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u), (const u64*)nullptr, maxd);
+    if (xbits > 0 && c->n_ranks > 1 && (1u << xbits) >= c->n_ranks) {
+      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)kpart,
+                 (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+                 c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
+                 (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+    } else {
+      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)kpart,
+                 (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
+                 c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
+                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
+                 (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+    }
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u, (const u64*)nullptr, maxd);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -579,6 +604,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
   if ((rc = ensure(c, c->ccounts, maxd * 4))) return rc;
   if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
+  if ((rc = set_k2ext(c, maxd, chunked ? c->sroff_d.p : (mr ? c->rx_roff.p : nullptr), n_src))) return rc;
   if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
@@ -588,7 +614,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
   if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
-  if ((rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS))) return rc;
+  if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
   HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
   // records per (cell, workgroup) segment of one group: (records / groups) / (1024 cells x 256 workgroups)
   const double total = (mr || chunked) ? (double)c->rx_records * 1.02
@@ -602,11 +628,17 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
     LAUNCH_LDS(c, "k_split", (k_split<u64, 0>), P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
                (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, mr ? rows_total : (u32)P3_NB, g * rows, rows, xbits,
                (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
-    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
-               (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
-               (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-               (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u),
-               (const u64*)(chunked ? c->sroff_d.p : nullptr), maxd);
+    if (n_src > 1) {  // (xbits >= log2 n_src by construction)
+      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
+                 (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
+                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+    } else {
+      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
+                 (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
+                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+    }
   }
   HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
@@ -750,10 +782,10 @@ int agg_local(p3_ctx* c) {
   if ((rc = ensure(c, c->sb_info, ((size_t)P3_NB << 5) * 16))) return rc;
   u64 h[6];
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
+  LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
              (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
              sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
-             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT, (const u64*)nullptr, (u64)0);
+             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
@@ -769,7 +801,7 @@ int agg_local(p3_ctx* c) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
                (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
                (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
-               (u32)P3_K2_AGG_OUT, (const u64*)nullptr, (u64)0);
+               (u32)P3_K2_AGG_OUT);
     HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h[3]) break;
@@ -1160,16 +1192,22 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             const u32 segcap_p = segcap_for((double)per_keys * H / (double)ns_total);
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
-            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                       (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                       (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), sbase, ns);
+            if (sweeps > 1) {
+              LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, true>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                         (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                         (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), sbase, ns);
+            } else {
+              LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+                         (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
+                         (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), 0u, ns);
+            }
           } else {
             if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
             const u64 cap_records = c->ppart.bytes / 4;
             LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
                    mm, H, slice_log2, (u32*)c->ghist.p);
             if ((rc = do_scan(c, st + 12))) return rc;
-            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
                        (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
                        (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
           }
@@ -1752,7 +1790,7 @@ int p3_mr_solid_bits(p3_ctx* c, uint64_t n_positions) {
   if (!c) return P3_EBADARG;
   if (!c->part_pos || !c->ns_recv.p) return fail(c, P3_ESTATE, "no received non-solid positions");
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = ensure(c, c->sing_cursor, 8 * P3_MAX_RANKS);
+  int rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS);
   if (rc) return rc;
   // the received count goes to the (now free) last word of the cursor array: the kernels read it from there
   u64* d_n = (u64*)c->sing_cursor.p + (P3_MAX_RANKS - 1);
