@@ -132,8 +132,12 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
       u32 nch = n / CHUNK;
       if (final_flush && (n % CHUNK)) nch++;
       const u32 wp = s.wpos[b];
-      if (est.segcap && wp + nch * CHUNK > est.segcap) {
-        if (q == 0) *est.ovf = 1;  // segment full: results are void, the host re-runs with exact offsets
+      const bool fits = !(est.segcap && wp + nch * CHUNK > est.segcap);
+      if (!fits) {
+        // segment full: the chunk is dropped, results are void and the host re-runs with exact offsets.  The write
+        // position stays put, so the counts reported below never exceed the capacity -- a reader launched before the
+        // host has seen the flag (single-synchronisation passes) stays inside the segment
+        if (q == 0) *est.ovf = 1;
       } else {
         uint4* dst = reinterpret_cast<uint4*>(out + s.segb[b] + wp);
         const uint4* row = s.rows + b * 8;
@@ -142,11 +146,14 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
       }
       if (!final_flush && q == 0) {
         s.cnt[b] = ((par ^ (nch & 1u)) << 31) | (n - nch * CHUNK);
-        s.wpos[b] = wp + nch * CHUNK;
+        if (fits) s.wpos[b] = wp + nch * CHUNK;
       }
     }
   }
-  if (final_flush && est.segcap) est.ghist_out[t * P3_NWG + blockIdx.x] = s.wpos[t] + n0;
+  if (final_flush && est.segcap) {
+    const u32 tot = s.wpos[t] + n0;  // (a final partial chunk that did not fit was not written either)
+    est.ghist_out[t * P3_NWG + blockIdx.x] = tot <= est.segcap ? tot : s.wpos[t];
+  }
 }
 
 // One insertion round: N fresh records per lane (bit i of `pend` = record i exists) plus the record carried over
