@@ -86,13 +86,20 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "kmer_split"  0 = auto: the same second-level partition for the passing k-mer records of the Bloom stage, taken from
  *                 an 8-way set split on; x+1 (2..11) = force x split bits (tests); "count_split" = 1 switches it off
  *                 as well.  p3_get_info "ksplit_xbits" reads back x.
+ *   "kmer_collect" position chunks, Bloom stage: 1 (default) = from four chunks on, the chunks' distinct passing k-mers
+ *                 are collected (in groups of as many chunks as fit in device memory), deduplicated once more
+ *                 (k_keys_scatter + the dedup machinery) and probed once per group instead of once per chunk;
+ *                 0 = never; 2 = from two chunks on.  "kmer_group" n = at most n chunks per group (tests; 0 = by
+ *                 memory).  p3_get_info "kmer_groups" reads back the groups probed in the last pass.
+ *   "lend"        position chunks: 1 = the Bloom stage's scratch buffers are carved from the count stage's partition
+ *                 buffer even when device memory is plentiful (tests; default 0 = only when it is short).
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 3x -- fewer bytes to
  *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
  *                 both forms record by record, so ranks need not agree.
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
- * "rs_log2", "distinct_kmers", "est_fallbacks", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
+ * "rs_log2", "distinct_kmers", "est_fallbacks", "kmer_groups", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 

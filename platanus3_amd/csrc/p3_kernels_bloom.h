@@ -669,6 +669,56 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restr
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
 }
 
+// ---- k_keys_scatter: partition a LIST of canonical k-mer keys by bucket (same record and bucket as k_kmer_scatter) --
+// Used when a large input was processed in position chunks: the chunks' distinct k-mers are collected and then
+// deduplicated once more, globally, before the probes are generated.  Estimated capacities only.  The list is the
+// concatenation of the chunks' dedup outputs, i.e. runs of thousands of keys of the SAME bucket, in the same
+// bucket order in every chunk.  Two things follow for the read pattern:
+//  * balance: a run must be spread over all workgroups (each (bucket, workgroup) segment has the capacity of its
+//    fair share) in pieces much smaller than run / 256 -- 16-key tiles, handed out round-robin over workgroups;
+//  * diversity: the stager drains ONE 16-record row per bucket and round, so the 256 tiles a workgroup reads per
+//    round should be of 256 different buckets.  The list is cut into 256 strips (one per quarter-wave slot of a
+//    workgroup) and strip j is walked from a start rotated by j/256 of its length, which also separates the strips
+//    that sit at the same offset of different chunks.
+template <int NW>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u64* __restrict__ keys, u64 n,
+                                                                 typename KRec<NW>::type* __restrict__ part, EstSeg est) {
+  typedef typename KRec<NW>::type REC;
+  constexpr int RW = (NW == 1) ? 4 : 2;
+  constexpr u32 SLOTS = (P3_PART_THREADS / 16) * RW;  // tiles per workgroup and round = strips
+  extern __shared__ __align__(16) u32 lds[];
+  const StageLds stg = stage_layout(lds);
+  stage_init(stg, nullptr, est);
+  const u64 n_tiles = (n + 15) / 16;
+  const u64 rounds = (n_tiles + (u64)SLOTS * P3_NWG - 1) / ((u64)SLOTS * P3_NWG);  // per strip: rounds * P3_NWG tiles
+  const u64 T = rounds * P3_NWG;
+  u64 r = 0;
+  stage_run<REC, RW>(stg, part, est, [&](REC (&rec)[RW], u32 (&bkt)[RW], u32& pend) -> bool {
+    if (r >= rounds) return false;
+    pend = 0;
+#pragma unroll
+    for (int t = 0; t < RW; t++) {
+      bkt[t] = 0;
+      const u32 j = (u32)t * (P3_PART_THREADS / 16) + (threadIdx.x >> 4);  // strip
+      u64 u = r * P3_NWG + blockIdx.x + (u64)j * rounds;                    // (j/SLOTS of the strip, whole rounds)
+      if (u >= T) u -= T;
+      const u64 i = ((u64)j * T + u) * 16 + (threadIdx.x & 15u);
+      if (i < n) {
+        const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
+        if constexpr (NW == 1) rec[t] = lo;
+        else {
+          rec[t].lo = lo;
+          rec[t].hi = hi;
+        }
+        bkt[t] = (u32)(khash<NW>(lo, hi) >> (64 - P3_PBITS));
+        pend |= 1u << t;
+      }
+    }
+    r++;
+    return true;
+  });
+}
+
 template <int NW, bool MULTI>  // MULTI: one of several sweeps over a vector of more than 1024 slices
 // totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
 // raises *cap_flag and writes nothing (the host re-runs with a larger buffer).

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "platanus3_amd.h"
@@ -32,6 +33,7 @@ struct KStat {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool borrowed = false;  // carved from the lent count-stage partition (p3_ctx::arena_*): never freed, see LendScope
 };
 
 }  // namespace
@@ -96,10 +98,25 @@ struct p3_ctx {
   bool chunk_acc = false;    // do_bloom_t: later chunk (keep the Bloom vector, OR into it), no seeds yet
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
+  // chunked Bloom stage under memory pressure: the count stage's partition buffer is lent to the k-mer stage's
+  // scratch buffers (kpart, klpart, dkeys, dall, ppart) instead of being freed (LendScope)
+  char* arena_p = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
   u64 chunk_w0[17] = {0};
   int ksplit_opt = 0;         // 0 = auto, x+1 (2..11) = force x split bits for the k-mer records (tests)
   u32 kxg = 0, hint_kxg = 0;  // split bits of the k-mer records' second-level partition (0 = not used)
   DevBuf klpart, zero8;
+  // position chunks, Bloom stage: kphase 1 = a chunk's distinct k-mers are appended to `dall` instead of being
+  // probed; kphase 2 = the collected list is partitioned (k_keys_scatter), deduplicated once more and probed
+  int kphase = 0;
+  u32 kgroups = 0;            // info: collected groups probed in the last chunked Bloom stage
+  bool kcollect_pass = true;  // this pass: cleared by the first chunk when the collection would not fit in memory
+  bool kcollect_ok = true;   // cleared when the collected list's partition overflowed its estimate
+  int lend_opt = 0;          // tests: 1 = lend the count partitions to the k-mer stage whatever the free memory
+  int kgroup_opt = 0;        // tests: at most this many chunks per collected group (0 = as many as fit in memory)
+  int kcollect_opt = 1;      // 0 = probe every chunk's k-mers directly (tests)
+  DevBuf dall;
+  u64 dall_n = 0, dall_cap = 0;
   u64 k2ext_h[2] = {0, 0};
   u64 distinct_cap = 0;      // entries of the count table outputs when sized from an estimate (position chunks)
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
@@ -166,14 +183,32 @@ int fail(p3_ctx* c, int code, const char* fmt, ...) {
                                       __FILE__, __LINE__);                                           \
   } while (0)
 
+void release(DevBuf& b);
+
+bool lendable(const p3_ctx* c, const DevBuf& b) {
+  return &b == &c->kpart || &b == &c->klpart || &b == &c->dkeys || &b == &c->dall || &b == &c->ppart;
+}
+
 int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return P3_OK;
-  if (b.p) {
-    HIPCHK(c, hipFree(b.p));
-    b.p = nullptr;
-    b.bytes = 0;
+  if (c->arena_p && lendable(c, b)) {
+    const size_t need = (bytes + 4095) & ~(size_t)4095;
+    if (c->arena_used + need <= c->arena_bytes) {
+      if (b.p && !b.borrowed) release(b);
+      b.p = c->arena_p + c->arena_used;
+      b.bytes = need;
+      b.borrowed = true;
+      c->arena_used += need;
+      return P3_OK;
+    }
   }
+  if (b.p) release(b);
+  static const bool trace = getenv("P3_TRACE_ALLOC") != nullptr;  // diagnostic: log every device (re)allocation >= 256 MiB
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
+  if (trace && bytes >= (256u << 20))
+    fprintf(stderr, "[p3] hipMalloc %.2f GiB: %.1f ms\n", (double)bytes / (1u << 30),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (e != hipSuccess) {
     b.p = nullptr;
     return fail(c, e == hipErrorOutOfMemory ? P3_ENOMEM : P3_EHIP, "hipMalloc(%zu) failed: %s", bytes,
@@ -184,10 +219,35 @@ int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 void release(DevBuf& b) {
-  if (b.p) (void)hipFree(b.p);
+  static const bool trace = getenv("P3_TRACE_ALLOC") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (b.p && !b.borrowed) (void)hipFree(b.p);
+  if (trace && b.p && !b.borrowed && b.bytes >= (256u << 20))
+    fprintf(stderr, "[p3] hipFree %.2f GiB: %.1f ms\n", (double)b.bytes / (1u << 30),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   b.p = nullptr;
   b.bytes = 0;
+  b.borrowed = false;
 }
+
+// Lends the memory of `owner` (not needed for the duration of the scope) to the lendable scratch buffers: ensure()
+// carves them from it instead of calling hipMalloc.  On exit every borrowed buffer is forgotten (the owner's next
+// user overwrites the memory).
+struct LendScope {
+  p3_ctx* c;
+  LendScope(p3_ctx* c_, const DevBuf& owner) : c(c_) {
+    c->arena_p = (char*)owner.p;
+    c->arena_bytes = owner.p ? owner.bytes : 0;
+    c->arena_used = 0;
+  }
+  ~LendScope() {
+    DevBuf* lent[] = {&c->kpart, &c->klpart, &c->dkeys, &c->dall, &c->ppart};
+    for (DevBuf* b : lent)
+      if (b->borrowed) release(*b);
+    c->arena_p = nullptr;
+    c->arena_bytes = c->arena_used = 0;
+  }
+};
 
 KStat* stat_for(p3_ctx* c, const char* name) {
   for (auto& s : c->kstats)
@@ -293,6 +353,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->reads_epoch++;
   c->hint_valid = false;
   c->est_ok = true;
+  c->kcollect_ok = true;
   c->distinct_cap = 0;
   c->host_windows = 0;
   c->pass_hint = 0;
@@ -1044,12 +1105,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   u64* st = (u64*)c->dstats.p;
   const bool have_s = c->count_mode == 2 && c->gate_mode == 2 && c->s_ready;
   if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
+  if (c->kphase != 2) HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
   if (!c->chunk_acc) HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-  if (have_s) {
-    // S was assembled by the count stage's return path
+  if (have_s || c->kphase == 2) {
+    // S was assembled by the count stage's return path (kphase 2: the gate has been applied chunk by chunk)
   } else if (c->count_mode == 2) {
     LAUNCH(c, "k_gate_regions", k_gate_regions, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
            (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p,
@@ -1061,7 +1122,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   }
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   const ModM mm = make_modm(m);
-  bool use_dedup = c->bloom_mode_opt != 1 && part_applicable(c);
+  bool use_dedup = c->bloom_mode_opt != 1 && (part_applicable(c) || c->kphase == 2);
   if (c->bloom_mode_opt == 2 && !use_dedup) return fail(c, P3_EBADARG, "dedup Bloom build forced but input too large");
   u64 h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (use_dedup) {
@@ -1072,14 +1133,23 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     double mean_k = (double)wg_window_bound(c) / P3_NB;
     if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
     if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
-    const u32 segcap_k = est ? segcap_for(mean_k) : 0;
+    if (c->kphase == 2) mean_k = (double)c->dall_n * 1.02 / ((double)P3_NB * P3_NWG);
+    // (kphase 2: the list holds same-bucket runs, one per chunk and dedup cell, and the scatter deals them out in
+    // 16-key tiles, so a (bucket, workgroup) segment receives its share give or take a tile per run: extra margin)
+    const u32 segcap_k = est ? segcap_for(mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
     if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
     if ((rc = ensure(c, c->kpart, (est ? (u64)P3_NB * P3_NWG * segcap_k : max_records) * sizeof(REC)))) return rc;
-    if ((rc = ensure(c, c->dkeys, (c->n_words * 32 + 1) * 8 * NW))) return rc;
+    if ((rc = ensure(c, c->dkeys, ((c->kphase == 2 ? c->dall_n : c->n_words * 32) + 1) * 8 * NW))) return rc;
     const size_t lds_sc = (size_t)P3_STAGE_WORDS * 4;
-    if (est) {
+    if (c->kphase == 2) {
+      if (!est) return fail(c, P3_ERETRY_INTERNAL, "global k-mer dedup needs the estimated-capacity partition");
+      if ((rc = fixed_segoff(c, segcap_k))) return rc;
+      HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
+      LAUNCH_LDS(c, "k_keys_scatter", (k_keys_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dall.p, c->dall_n,
+                 (REC*)c->kpart.p, (EstSeg{segcap_k, (u32*)c->ghist.p, st + 27}));
+    } else if (est) {
       // estimated segment capacities: the scatter evaluates the gate itself (P, statistics) -- no histogram pass
       if ((rc = fixed_segoff(c, segcap_k))) return rc;
       LAUNCH_LDS(c, "k_kmer_scatter", (k_kmer_scatter<NW, true>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->fw.p,
@@ -1101,7 +1171,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     // plain form: one workgroup per sub-bucket, each reading the whole bucket (2^sbits reads of every record);
     // split form (kxg > 0), for large inputs: the k-mer records are partitioned a second time (k_split) into
     // 1024 cells per group of 1024 >> kxg buckets and every cell is read once
-    const double krecords = mean_k * (double)P3_NB * active_wgs(c->n_words);  // estimate of the passing k-mers
+    const double krecords = c->kphase == 2 ? (double)c->dall_n * 1.02
+                                           : mean_k * (double)P3_NB * active_wgs(c->n_words);  // estimate of the passing k-mers
     auto dedup_once = [&](u32 sb, u32 xg) -> int {
       HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
       if (!xg) {
@@ -1112,7 +1183,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       }
       int r2;
       const u32 groups = 1u << xg, rows = P3_NB >> xg;
-      const u32 segcap2 = segcap_for(krecords / ((double)groups * P3_NB * P3_NWG));
+      // (kphase 2: the lumps of the tiled key scatter come through segment by segment)
+      const u32 segcap2 = segcap_for(krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? c->chunks * 64u : 0u);
       if ((r2 = ensure(c, c->klpart, (u64)P3_NB * P3_NWG * segcap2 * sizeof(REC)))) return r2;
       if ((r2 = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return r2;
       if ((r2 = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return r2;
@@ -1144,6 +1216,11 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
           sbits = c->ksbits;
         }
       }
+      if (c->kphase == 2) {  // the collected list: cells of at most 4 records per set slot, then grown on overflow
+        sbits = 0;
+        kxg = 1;
+        while (kxg < 10 && (c->dall_n >> kxg) / P3_NB > ((u64)4 << ts_log2)) kxg++;
+      }
       if (c->ksplit_opt >= 2) {  // tests: force the split form
         kxg = (u32)c->ksplit_opt - 1;
         sbits = 0;
@@ -1165,11 +1242,44 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         else sbits++;
       }
     }
-    if (use_dedup) {
+    if (use_dedup && c->kphase == 1 && !c->dall_cap) {
+      // first chunk: the global deduplication needs the list, its partition, the second-level partition and the
+      // key output at once (about 4.5x the list).  When the lists of all chunks do not fit (config #4: 16-byte keys
+      // of 10 G bases) the chunks are collected in GROUPS of as many as do; below two, chunk by chunk as before
+      const double per_chunk = ((double)h[0] * 1.3 + (double)(1u << 16)) * 8 * NW * 4.5;
+      size_t mem_free = 0, mem_total = 0;
+      u32 fit = 0;
+      if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
+        fit = (u32)std::min(64.0, ((double)mem_free + (double)(c->arena_bytes - c->arena_used) + (double)c->dall.bytes + (double)c->klpart.bytes) * 0.9 /
+                                     per_chunk);
+      if (c->kgroup_opt) fit = std::min(fit, (u32)c->kgroup_opt);
+      if (fit < 2) {
+        c->kphase = 0;
+        c->kcollect_pass = false;
+      } else {
+        const u64 cap = (u64)((double)h[0] * 1.3 + (double)(1u << 16)) * std::min(fit, c->chunks);
+        if ((rc = ensure(c, c->dall, cap * 8 * NW))) return rc;
+        c->dall_cap = cap;
+      }
+    }
+    if (use_dedup && c->kphase == 1) {
+      // position chunk: keep this chunk's distinct k-mers for the global deduplication instead of probing them now
       c->ksbits = sbits;
       c->kxg = kxg;
       c->ksbits_epoch = c->reads_epoch;
       c->ksbits_k = k;
+      c->n_distinct_k = h[0];
+      if (c->dall_n + h[0] > c->dall_cap) return fail(c, P3_ECAPACITY, "collected k-mer list full");
+      HIPCHK(c, hipMemcpyAsync((u64*)c->dall.p + c->dall_n * NW, c->dkeys.p, h[0] * 8 * NW, hipMemcpyDeviceToDevice, c->stream));
+      c->dall_n += h[0];
+      c->bloom_mode = 3;
+    } else if (use_dedup) {
+      if (c->kphase != 2) {
+        c->ksbits = sbits;
+        c->kxg = kxg;
+        c->ksbits_epoch = c->reads_epoch;
+        c->ksbits_k = k;
+      }
       if (!c->spec) c->n_distinct_k = h[0];
       // slices of 2^slice_log2 bits (<= 2^20: 128 KiB of LDS), 1024 per sweep; a vector of more than 2^30 bits takes
       // several sweeps over the distinct keys (estimated-capacity form only), each keeping the probes of its slices
@@ -1227,6 +1337,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       HIPCHK(c, hipMemsetAsync(st + 8, 0, 8 * 8, c->stream));
     }
   }
+  if (!use_dedup && c->kphase == 2) return fail(c, P3_ECAPACITY, "global k-mer dedup overflowed at every split");
+  if (!use_dedup && c->kphase == 1) return fail(c, P3_ECAPACITY, "no deduplicated keys to collect");
   if (!use_dedup) {
     LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
            (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p,
@@ -1244,6 +1356,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
+  if (c->kphase == 2 && hall[27]) {
+    c->kcollect_ok = false;  // (the per-chunk form still works: no need to give up the estimates altogether)
+    return fail(c, P3_ERETRY_INTERNAL, "collected k-mer partition: estimated segment capacity exceeded");
+  }
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     c->est_ok = false;
     c->est_fallbacks++;
@@ -1265,8 +1381,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   c->bstats.n_windows_k = hall[8];
   c->bstats.n_passing = hall[9];
   c->bstats.n_seed_reads = hall[10];
-  c->pass_hint = hall[9];
-  c->pass_hint_k = k;
+  if (c->kphase != 2) {
+    c->pass_hint = hall[9];
+    c->pass_hint_k = k;
+  }
   c->k = k;
   c->m = m;
   c->H = H;
@@ -1404,21 +1522,69 @@ template <int NW>
 int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
   int rc;
   const u64 nwa = c->n_words + P3_PAD_WORDS;
+  const u64 bwords = (m + 63) / 64;
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   if ((rc = ensure(c, c->P, nwa * 4))) return rc;
+  // The count stage is done with its partitions (tens of GB).  Freeing them is not an option: a hipMalloc that
+  // follows the hipFree of a buffer this size was measured at 1-3 s (32M reads; 0.3 ms otherwise), ten times the
+  // kernels of the pass.  When the k-mer buffers (about as large again) might not fit beside them, the partition
+  // buffer is LENT to them for the duration of this stage instead.
+  size_t mem_free0 = 0, mem_total0 = 0;
+  const bool tight = hipMemGetInfo(&mem_free0, &mem_total0) != hipSuccess || mem_free0 < 2 * c->part8c.bytes || c->lend_opt;
+  DevBuf nothing;
+  LendScope lend(c, tight ? c->part8c : nothing);
+  if ((rc = ensure(c, c->bloom, bwords * 8))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords * 8, c->stream));
+  // Every chunk sees most of the genome's k-mers again, so probing chunk by chunk repeats the probe work `chunks`
+  // times.  Instead the chunks' distinct k-mers are collected, deduplicated once more (k_keys_scatter + the same
+  // dedup machinery) and probed once.  A chunk whose keys do not fit the collection is probed directly.
+  const bool collect = c->est_ok && c->sizing_opt != 1 && c->bloom_mode_opt != 1 && c->kcollect_opt && c->kcollect_ok &&
+                       (c->chunks >= 4 || c->kcollect_opt == 2);  // (two chunks: the extra dedup costs more than it saves)
+  c->dall_n = 0;
+  c->dall_cap = 0;
+  c->kcollect_pass = true;
   u64 nv = 0, np = 0, nd = 0;
+  c->kgroups = 0;
   {
     ChunkView view(c);
+    // probe the collected list (one group of chunks) and empty it
+    auto flush_group = [&]() -> int {
+      if (!c->dall_n) return P3_OK;
+      view.restore();  // the whole stream again (the probes do not look at it, the buffers' sizes do)
+      c->chunk_acc = true;
+      c->kphase = 2;
+      int r2 = do_bloom_t<NW>(c, k, m, H);
+      c->kphase = 0;
+      c->chunk_acc = false;
+      if (r2) return r2;
+      nd += c->n_distinct_k;
+      c->dall_n = 0;
+      c->kgroups++;
+      return P3_OK;
+    };
     for (u32 ci = 0; ci < c->chunks; ci++) {
       view.set(ci);
-      c->chunk_acc = ci > 0;
+      c->chunk_acc = true;  // (the vector was zeroed above)
+      c->kphase = (collect && c->kcollect_pass) ? 1 : 0;
+      const bool collecting = c->kphase == 1;
       rc = do_bloom_t<NW>(c, k, m, H);
+      if (rc == P3_ECAPACITY && collecting) {  // collection full (or no dedup): this chunk goes in directly
+        c->kphase = 0;
+        rc = do_bloom_t<NW>(c, k, m, H);
+        if (!rc) nd += c->n_distinct_k;
+      } else if (!rc && !(collecting && c->kcollect_pass)) {
+        nd += c->n_distinct_k;
+      }
+      c->kphase = 0;
       c->chunk_acc = false;
       if (rc) return rc;
       nv += c->bstats.n_windows_k;
       np += c->bstats.n_passing;
-      nd += c->n_distinct_k;
+      // the next chunk's list will be about as long as this one's: no room left means the group is complete
+      if (c->dall_n && ci + 1 < c->chunks && c->dall_n + (u64)((double)c->n_distinct_k * 1.15) > c->dall_cap)
+        if ((rc = flush_group())) return rc;
     }
+    if ((rc = flush_group())) return rc;
   }
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st + 10, 0, 8, c->stream));
@@ -1497,7 +1663,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
-                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8};
+                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1536,6 +1702,13 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "lend") {
+    c->lend_opt = value ? 1 : 0;
+  } else if (n == "kmer_group") {
+    if (value < 0 || value > 64) return fail(c, P3_EBADARG, "kmer_group must be in [0,64]");
+    c->kgroup_opt = (int)value;
+  } else if (n == "kmer_collect") {
+    c->kcollect_opt = (int)value;  // 0 off, 1 automatic (four chunks or more), 2 always
   } else if (n == "kmer_split") {
     if (value < 0 || value > 11) return fail(c, P3_EBADARG, "kmer_split must be in [0,11]");
     c->ksplit_opt = (int)value;
@@ -1576,6 +1749,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "split_xbits") *value = c->split_xbits;
   else if (n == "chunks") *value = c->chunks;
   else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
+  else if (n == "kmer_groups") *value = (int64_t)c->kgroups;
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);

@@ -522,15 +522,28 @@ def test_position_chunks_small(oracle, chunks, k):
     m, H = oracle.estimate_bloom(int(b.size), k)
     c = capi.Context(0)
     c.set_option("chunks", chunks)
+    # kmer_collect: 0 = every chunk probes its own k-mers, 2 = the chunks' k-mers are collected and deduplicated once
+    # more before the probes (the default, 1, does that from four chunks on)
+    # kmer_group: at most that many chunks per collected list (in production: as many as fit in device memory)
+    c.set_option("kmer_collect", {2: 2, 4: 1, 8: 0, 16: 2}[chunks])
+    if chunks == 16:
+        c.set_option("kmer_group", 5)
+    if chunks in (4, 16):
+        # the count stage's partition buffer is lent to the k-mer stage's scratch buffers (in production: only when
+        # device memory is short) -- every pass carves them anew
+        c.set_option("lend", 1)
     run_and_compare(c, oracle, (b, o), k, m, H)
     assert c.get_info("chunks") == chunks and c.get_info("count_mode") == 2 and c.get_info("gate_mode") == 2
+    assert c.get_info("est_fallbacks") == 0
+    # (16 chunks, at most 5 per group: the list's fixed slack dominates at this size, so the groups come out larger)
+    assert c.get_info("kmer_groups") in {2: (1,), 4: (1,), 8: (0,), 16: (2, 3, 4)}[chunks]
     if chunks == 4:
         # the count table outputs are sized from an estimate of the distinct keys; far too small a table must be
         # noticed by the count kernel (no write past it) and grown by doubling
         c.set_option("distinct_cap", 3000)
     c.run_pass(k, m, H)
     c.run_pass(k, m, H)
-    assert c.get_info("chunks") == chunks
+    assert c.get_info("chunks") == chunks and c.get_info("est_fallbacks") == 0
     keys, counts = c.export_counts()
     ekeys, ecounts = oracle.count_short((b, o), min_len=k)
     ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)

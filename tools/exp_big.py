@@ -13,11 +13,14 @@ m, H = bloom_sizing(int(b.size), k)
 print("%d x %d bp = %.2f G bases, m=%d H=%d (synth %.1f s)" % (R, L, b.size / 1e9, m, H, time.time() - t0), flush=True)
 c = capi.Context(0)
 t0 = time.time(); c.load_reads(b, o, k); print("load %.1f s" % (time.time() - t0), flush=True)
-for i in range(2):
+for i in range(int(os.environ.get('P3_PASSES', '2'))):
     t0 = time.perf_counter(); c.run_pass(k, m, H); dt = time.perf_counter() - t0
     nk = R * (L - k + 1)
     print("pass %d: %.1f ms device, %.1f ms wall = %.2f G k-mers/s; chunks=%d split_xbits=%d count_mode=%d bloom_mode=%d" %
           (i, c.timings()["ms_total"], dt * 1e3, nk / dt / 1e9, c.get_info("chunks"), c.get_info("split_xbits"), c.get_info("count_mode"), c.get_info("bloom_mode")), flush=True)
+    import ctypes as _C
+    c.L.p3_last_error.restype = _C.c_char_p
+    print("   est_fallbacks=%d ksplit_xbits=%d ksbits=%d last_error=%r" % (c.get_info("est_fallbacks"), c.get_info("ksplit_xbits"), c.get_info("ksbits"), c.L.p3_last_error(c.h)), flush=True)
 print(c.count_stats(), c.bloom_stats(), flush=True)
 assert c.count_stats()["n_windows"] == R * (L - 20)
 c.reset_kernel_stats(); c.set_profiling(True); c.run_pass(k, m, H); c.set_profiling(False)
