@@ -8,9 +8,14 @@
 // Build:  g++ -std=c++17 -O2 -I<repo>/include -I<repo>/platanus3_amd/host platanus3_main.cpp
 //             -L<repo>/platanus3_amd/csrc -lplatanus3_amd -Wl,-rpath,<repo>/platanus3_amd/csrc -pthread -o platanus3
 //
+// The stages hand their results on in HBM (AssembleResident); PLATANUS3_MATERIALISE=1 runs the reference-typed
+// Assemble<B> of the shim instead (same outputs; seconds of host time for the STL containers).
+//
 // What differs from the reference binary, on purpose: every k in [21,64] is dispatched (its switch has only 21, 25
 // and 63 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
 // graph closure explodes, no GPU -- ends with a message on stderr and exit status 3 rather than a silent "finish".
+#include <cstdlib>
+
 #include "platanus3_shim.hpp"
 
 namespace {
@@ -26,7 +31,10 @@ struct Run {
     opt.EstimateBloomfilter(reads.all_bases, log);
     log.WriteLog("read file loaded");
     opt.PrintParameters(log);
-    const int status = Assemble_k(reads, opt, log);
+    // PLATANUS3_MATERIALISE=1: go through the reference-typed containers (KmerCount, BF<bitset<2k>>, the graph's
+    // maps) of Assemble<B>, as a caller written against them would; default: everything stays on the device
+    const char* mat = std::getenv("PLATANUS3_MATERIALISE");
+    const int status = (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
     if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..64)\n";
     log.WriteLog("finish");
     return status == 0 ? 0 : 3;

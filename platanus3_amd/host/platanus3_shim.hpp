@@ -522,6 +522,38 @@ int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
   return 0;
 }
 
+// Same steps, same log lines, same output file as Assemble<B> above, but nothing is copied back to the host between
+// the stages: the count table, the Bloom vector, the seeds and the graph stay in HBM from p3_load_reads to
+// p3_write_gfa (the command line has no use for KmerCount / BF::m_bits / the three graph maps -- filling them is
+// 9 of the 10 s of a 1 M-read run).  k is checked by the library (21..64); other k return 1 like Assemble_k.
+inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& logging) {
+  if (options.kmer_length < 21 || options.kmer_length > 64) return 1;
+  logging.WriteLog("Assemble");
+  p3shim::Session& s = p3shim::Session::get();
+  s.load(input_reads.reads, options.kmer_length);
+  p3_ctx* ctx = s.context();
+  p3shim::check(ctx, p3_count_short(ctx), "p3_count_short");
+  s.counted = true;
+  logging.WriteLog("counted short kmer");
+  p3shim::check(ctx, p3_make_bloom(ctx, options.kmer_length, options.filter_size, options.num_hashes), "p3_make_bloom");
+  logging.WriteLog("bloom filter loaded");
+  logging.WriteLog("get seed kmer");
+  // size of the seed set (distinct forward strings, one candidate per read)
+  p3_bloom_stats bs;
+  p3shim::check(ctx, p3_get_bloom_stats(ctx, &bs), "p3_get_bloom_stats");
+  const uint64_t cap = bs.n_seed_reads ? bs.n_seed_reads : 1;
+  std::vector<uint64_t> keys(cap * (uint64_t)((2 * options.kmer_length + 63) / 64));
+  uint64_t n_seeds = 0;
+  p3shim::check(ctx, p3_export_seeds(ctx, keys.data(), cap, &n_seeds), "p3_export_seeds");
+  logging.WriteLog("seed kmer num= " + std::to_string(n_seeds));
+  logging.WriteLog("start graph extention");
+  p3shim::check(ctx, p3_build_graph(ctx), "p3_build_graph");
+  logging.WriteLog("de bruijn graph loaded");
+  logging.WriteLog("count node coverage");  // (accumulated by p3_build_graph)
+  p3shim::check(ctx, p3_write_gfa(ctx, "./de_bruijn_graph.gfa"), "p3_write_gfa");
+  return 0;
+}
+
 // Every k the device path supports (21..64) is dispatched -- the reference's switch (src/Assemble.cpp:31-53) only
 // has 21, 25 and 63 in that range; like there, any other k returns 1 without doing anything.
 inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging) {

@@ -115,10 +115,13 @@ def test_loader_fuzz_against_reference(probe, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("materialise", [0, 1])
 @pytest.mark.parametrize("name", ["synth400_k21", "synth2000_k31", "synth2000_k31_m24", "synth3000_k51", "long40_k63"])
-def test_command_line_end_to_end(tmp_path_factory, tmp_path, name):
+def test_command_line_end_to_end(tmp_path_factory, tmp_path, name, materialise):
     """platanus3 -i reads.fasta -k K [-m M] -t 1: the GFA written to the working directory equals the reference's
-    (canonical form); the Bloom sizing is the command line's own (EstimateBloomfilter or -m with H = 10)."""
+    (canonical form); the Bloom sizing is the command line's own (EstimateBloomfilter or -m with H = 10).
+    materialise=0: the stages hand their results on in HBM (AssembleResident, the default); 1: through the
+    reference-typed containers of Assemble<B> (PLATANUS3_MATERIALISE=1).  Same log lines either way."""
     from test_oracle_dbg import check_against_golden, load_dbg_reads
     case = [c for c in json.load(open(os.path.join(GOLDEN, "dbg_cases.json"))) if c["name"] == name][0]
     exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
@@ -128,10 +131,17 @@ def test_command_line_end_to_end(tmp_path_factory, tmp_path, name):
         for i in range(off.size - 1):
             f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
     args = [exe, "-i", fa, "-k", str(case["k"]), "-t", "1"] + (["-m", str(case["m"])] if case["H"] == 10 else [])
-    subprocess.check_call(args, cwd=str(tmp_path), timeout=180)
+    subprocess.check_call(args, cwd=str(tmp_path), timeout=180, env=dict(os.environ, PLATANUS3_MATERIALISE=str(materialise)))
     check_against_golden(case, open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
     log = open(os.path.join(str(tmp_path), "platanus3.log")).read()
     assert "filter_size : %d" % case["m"] in log and "num_hashes : %d" % case["H"] in log and log.rstrip().endswith("finish")
+    steps = [l for l in log.split("\n") if not l.startswith(("all_bases", "item_number", "get filter_size", "readfile_name",
+                                                             "filter_size", "num_hashes", "kmer_length", "error_rate"))]
+    assert [l.split("=")[0] for l in steps if l] == [
+        "read file loaded", "Assemble", "counted short kmer", "bloom filter loaded", "get seed kmer", "seed kmer num",
+        "start graph extention", "de bruijn graph loaded", "count node coverage", "finish"]
+    if "n_seeds" in case:
+        assert "seed kmer num= %d" % case["n_seeds"] in log
 
 
 def test_command_line_without_input_prints_usage(tmp_path_factory, tmp_path):
