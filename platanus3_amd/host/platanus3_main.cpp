@@ -27,6 +27,7 @@ struct Run {
   // steps 2..5 of the reference's main: load, size the filter from the loaded bases, report, assemble
   int assemble() {
     ReadFile reads(opt);
+    if (std::getenv("PLATANUS3_TIMING")) log.WriteLog("(start)");
     reads.LoadFile();
     opt.EstimateBloomfilter(reads.all_bases, log);
     log.WriteLog("read file loaded");

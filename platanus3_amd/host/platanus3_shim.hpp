@@ -24,6 +24,8 @@
 #include <unistd.h>
 
 #include <array>
+#include <chrono>
+#include <cstdlib>
 #include <bitset>
 #include <cmath>
 #include <cstdint>
@@ -51,6 +53,13 @@ class Logging {  // src/Logging.cpp:7-23 (append-per-message log; kept for signa
   std::string log_file = "./platanus3.log";
   void WriteLog(const std::string& text) {
     std::lock_guard<std::mutex> lock(mtx_log);
+    // PLATANUS3_TIMING=1: every log message also goes to stderr with the seconds since the first message
+    static const bool timing = std::getenv("PLATANUS3_TIMING") != nullptr;
+    if (timing) {
+      static const auto t0 = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[%8.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                   text.c_str());
+    }
     if (FILE* f = std::fopen(log_file.c_str(), "a")) {
       std::fputs(text.c_str(), f);
       std::fputc('\n', f);

@@ -20,7 +20,8 @@ for name, n, k, seed in (("config1", 10_000, 21, 1), ("config2", 1_000_000, 31, 
     wd = os.path.join(tmp, name)
     os.makedirs(wd)
     t1 = time.time()
-    subprocess.check_call([exe, "-i", fa, "-k", str(k), "-t", "8"], cwd=wd, timeout=1500)
+    subprocess.check_call([exe, "-i", fa, "-k", str(k), "-t", "8"], cwd=wd, timeout=1500,
+                          env=dict(os.environ, PLATANUS3_TIMING="1") if os.environ.get("P3_CLI_TIMING") else None)
     t2 = time.time()
     gfa = os.path.join(wd, "de_bruijn_graph.gfa")
     print("%s: %d reads k=%d: wrote FASTA %.1f s, command line %.2f s, GFA %d bytes, %d lines" %
