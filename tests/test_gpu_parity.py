@@ -211,6 +211,44 @@ def test_protocol_single_rank(oracle, gate):
     c.close()
 
 
+def test_protocol_over_rccl_one_rank(oracle):
+    """The protocol's collectives issued through torch.distributed on a REAL RCCL process group of one rank (the
+    test box has one GPU): device-pointer tensor views, all_to_all_single with split sizes, all_gather_into_tensor
+    and the scalar reductions go through the library bench.py uses at N > 1.  Same results as the oracle."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from platanus3_amd.pipeline import Pipeline, TorchComm
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        b, o = synth.reads(seed=32, total_reads=20000, read_len=150)
+        k = 31
+        m, H = oracle.estimate_bloom(int(b.size), k)
+        for gate in (2, 1):
+            pipe = Pipeline(device=0, rank=0, world=1, force_protocol=True, comm=TorchComm(torch.device("cuda", 0)))
+            pipe.ctx.set_option("gate_mode", gate)
+            pipe.load_reads(b, o, min_len=k)
+            pipe.run_pass(k, m, H)
+            pipe.run_pass(k, m, H)
+            c = pipe.ctx
+            keys, counts = c.export_counts()
+            ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+            assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+            ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+            c.k, c.m, c.H = k, m, H
+            assert np.array_equal(c.export_bloom(), ebloom)
+            assert [capi.decode_key(r, k) for r in c.export_seeds()] == eseeds
+            assert pipe.global_distinct() == ekeys.size
+            c.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_config2_full_size_against_reference_checksums(ctx):
     """BASELINE config #2 at FULL size (1 M x 150 bp, k=31): sha256 of the exported count table, Bloom words
     (default sizing and the '-m 2^30' H=10 run) and seed list against checksums the REAL reference produced on
