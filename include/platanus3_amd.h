@@ -91,6 +91,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 (k_keys_scatter + the dedup machinery) and probed once per group instead of once per chunk;
  *                 0 = never; 2 = from two chunks on.  "kmer_group" n = at most n chunks per group (tests; 0 = by
  *                 memory).  p3_get_info "kmer_groups" reads back the groups probed in the last pass.
+ *   "est_boost"   1 (default) = an overflowing estimated-capacity partition (skewed keys) is repeated with larger
+ *                 estimated capacities (+50 %, then +150 % of the mean) before exact offsets are used; 0 = straight to
+ *                 exact offsets.  p3_get_info "est_level" reads back 0..2 (level in use) or 3 (exact).
  *   "lend"        position chunks: 1 = the Bloom stage's scratch buffers are carved from the count stage's partition
  *                 buffer even when device memory is plentiful (tests; default 0 = only when it is short).
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
@@ -99,7 +102,7 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
  *                 both forms record by record, so ranks need not agree.
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
- * "rs_log2", "distinct_kmers", "est_fallbacks", "kmer_groups", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
+ * "rs_log2", "distinct_kmers", "est_fallbacks", "est_level", "kmer_groups", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 

@@ -51,6 +51,7 @@ struct p3_ctx {
   const u64* d_offsets = nullptr;
   DevBuf owned_bases, owned_offsets;
   u64 n_reads = 0, n_bases = 0, n_words = 0;
+  u64 n_words_all = 0;  // n_words of the whole input (n_words is narrowed while a position chunk is in view)
   u64 host_windows = 0;  // sum over admitted reads of (L - 20), when the offsets were seen on the host (else 0)
   u32 min_len = 0;
   bool have_reads = false;
@@ -75,7 +76,8 @@ struct p3_ctx {
   int tsk_log2_opt = 14;
   int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)
   int sizing_opt = 0;       // 0 auto (estimated segment capacities on one rank), 1 exact (histogram + scan)
-  bool est_ok = true;       // cleared when an estimated segment overflowed (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
+  u32 est_boost = 0;        // skew response: 0 / 1 / 2 = segment capacities of the estimate + 0 / 50 / 150 % of the mean
+  bool est_ok = true;       // cleared when an estimated segment overflowed at the last boost level (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0, ksbits_k = 0;
   u64 ksbits_epoch = ~0ull;
   DevBuf kpart, dkeys, ppart, scan_tmp;
@@ -112,6 +114,7 @@ struct p3_ctx {
   u32 kgroups = 0;            // info: collected groups probed in the last chunked Bloom stage
   bool kcollect_pass = true;  // this pass: cleared by the first chunk when the collection would not fit in memory
   bool kcollect_ok = true;   // cleared when the collected list's partition overflowed its estimate
+  int boost_opt = 0;         // tests: 1 = no boost levels (an overflowing estimate goes straight to exact offsets)
   int lend_opt = 0;          // tests: 1 = lend the count partitions to the k-mer stage whatever the free memory
   int kgroup_opt = 0;        // tests: at most this many chunks per collected group (0 = as many as fit in memory)
   int kcollect_opt = 1;      // 0 = probe every chunk's k-mers directly (tests)
@@ -346,6 +349,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->n_reads = n_reads;
   c->n_bases = n_bases;
   c->n_words = (n_bases + 31) / 32;
+  c->n_words_all = c->n_words;
   c->min_len = min_len;
   c->have_reads = true;
   c->packed = c->counted = c->bloomed = false;
@@ -353,6 +357,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->reads_epoch++;
   c->hint_valid = false;
   c->est_ok = true;
+  c->est_boost = 0;
   c->kcollect_ok = true;
   c->distinct_cap = 0;
   c->host_windows = 0;
@@ -415,12 +420,26 @@ int do_count_direct(p3_ctx* c) {
 // limits of the partitioned form: 32-bit record indices
 bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG * P3_NB < (1ull << 31); }
 
-// Estimated-capacity segments (single rank): capacity = mean + 6 sigma + slack records, multiple of 16
-u32 segcap_for(double mean) {
+// Estimated-capacity segments: capacity = mean + 6 sigma + slack records, multiple of 16.  Keys that are not
+// hash-spread (low-complexity repeats: one 21-mer with thousands of instances) overflow such a segment; the response
+// is graded (est_overflowed): the stage is repeated with 50 %, then 150 % of the mean on top, and only then with
+// exact offsets (histogram + scan) -- which the position-chunk form of large inputs does not have.
+u32 segcap_for(const p3_ctx* c, double mean) {
   // (the constant slack matters for tiny means only; every 16 records of capacity is 16 records of gap the readers
   // step over, ~2.4 % of a 672-record segment)
-  const double c = mean + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) + (mean >= 256.0 ? 16.0 : 32.0);
-  return ((u32)c + 15u) & ~15u;
+  static const double boost[3] = {0.0, 0.5, 1.5};
+  const double v = mean * (1.0 + boost[c->est_boost < 3 ? c->est_boost : 2]) + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) +
+                   (mean >= 256.0 ? 16.0 : 32.0);
+  return ((u32)v + 15u) & ~15u;
+}
+
+// an estimated-capacity segment overflowed: next boost level, or no more estimates for these reads
+void est_overflowed(p3_ctx* c) {
+  c->est_fallbacks++;
+  // (beyond 2^31 positions the partitions are tens of GB: one level only)
+  const u32 top = (c->n_words_all ? c->n_words_all : c->n_words) * 32 > (1ull << 31) ? 1u : 2u;
+  if (c->est_boost < top && c->boost_opt != 1) c->est_boost++;
+  else c->est_ok = false;
 }
 
 bool est_mode(const p3_ctx* c) { return c->n_ranks == 1 && !c->protocol && c->est_ok && c->sizing_opt != 1; }
@@ -469,7 +488,7 @@ int part_local(p3_ctx* c, bool with_pos) {
   // stream-word bound
   const double mean21 = c->host_windows ? (double)c->host_windows * 1.02 / ((double)P3_NB * active_wgs(c->n_words))
                                         : (double)wg_window_bound(c) / P3_NB;
-  const u32 segcap = est ? segcap_for(mean21) : 0;
+  const u32 segcap = est ? segcap_for(c, mean21) : 0;
   if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
@@ -629,8 +648,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
-    c->est_ok = false;
-    c->est_fallbacks++;
+    est_overflowed(c);
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
   *overflowed = h[3] != 0;
@@ -680,7 +698,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   // records per (cell, workgroup) segment of one group: (records / groups) / (1024 cells x 256 workgroups)
   const double total = (mr || chunked) ? (double)c->rx_records * 1.02
                                        : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
-  const u32 segcap = segcap_for(total / ((double)groups * P3_NB * P3_NWG));
+  const u32 segcap = segcap_for(c, total / ((double)groups * P3_NB * P3_NWG));
   if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
   LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
@@ -713,8 +731,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h[26]) {
-    c->est_ok = false;
-    c->est_fallbacks++;
+    est_overflowed(c);
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
   if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
@@ -768,7 +785,7 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
   if (est) {
     u64 per = (n_est + n_est / 16 + P3_NWG - 1) / P3_NWG;
     per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
-    const u32 segcap = segcap_for((double)per / (ns ? ns : 1));
+    const u32 segcap = segcap_for(c, (double)per / (ns ? ns : 1));
     if ((rc = ensure(c, c->ns_part, (u64)P3_NB * P3_NWG * segcap * 4))) return rc;
     if ((rc = fixed_segoff(c, segcap))) return rc;
     LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
@@ -980,7 +997,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   u64 per = (wc + P3_NWG - 1) / P3_NWG;
   per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
   const double mean21 = hw0 > 0 ? (hw0 + 1) * 1.02 / ((double)P3_NB * active_wgs(wc)) : (double)(per * 32) / P3_NB;
-  const u64 region = (u64)P3_NB * P3_NWG * (segcap_for(mean21) + 16);  // records per chunk partition (a little slack)
+  const u64 region = (u64)P3_NB * P3_NWG * (segcap_for(c, mean21) + 16);  // records per chunk partition (a little slack)
   const size_t desc = (size_t)P3_NB * P3_NWG * 4;
   if ((rc = ensure(c, c->part8c, (u64)C * region * 8))) return rc;
   if ((rc = ensure(c, c->rx_ghist_buf, (size_t)C * desc))) return rc;
@@ -1003,8 +1020,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
       HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (h[26]) {
-        c->est_ok = false;
-        c->est_fallbacks++;
+        est_overflowed(c);
         return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
       }
       windows[ci] = h[5];
@@ -1055,8 +1071,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
       HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (h[26]) {
-        c->est_ok = false;
-        c->est_fallbacks++;
+        est_overflowed(c);
         return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
       }
     }
@@ -1136,7 +1151,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (c->kphase == 2) mean_k = (double)c->dall_n * 1.02 / ((double)P3_NB * P3_NWG);
     // (kphase 2: the list holds same-bucket runs, one per chunk and dedup cell, and the scatter deals them out in
     // 16-key tiles, so a (bucket, workgroup) segment receives its share give or take a tile per run: extra margin)
-    const u32 segcap_k = est ? segcap_for(mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
+    const u32 segcap_k = est ? segcap_for(c, mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
     if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
@@ -1184,7 +1199,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       int r2;
       const u32 groups = 1u << xg, rows = P3_NB >> xg;
       // (kphase 2: the lumps of the tiled key scatter come through segment by segment)
-      const u32 segcap2 = segcap_for(krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? c->chunks * 64u : 0u);
+      const u32 segcap2 = segcap_for(c, krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? c->chunks * 64u : 0u);
       if ((r2 = ensure(c, c->klpart, (u64)P3_NB * P3_NWG * segcap2 * sizeof(REC)))) return r2;
       if ((r2 = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return r2;
       if ((r2 = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return r2;
@@ -1299,7 +1314,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
             const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
             const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
-            const u32 segcap_p = segcap_for((double)per_keys * H / (double)ns_total);
+            const u32 segcap_p = segcap_for(c, (double)per_keys * H / (double)ns_total);
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             if (sweeps > 1) {
@@ -1361,8 +1376,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     return fail(c, P3_ERETRY_INTERNAL, "collected k-mer partition: estimated segment capacity exceeded");
   }
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
-    c->est_ok = false;
-    c->est_fallbacks++;
+    est_overflowed(c);
     c->counted = c->counted && !hall[26];
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
   }
@@ -1702,6 +1716,8 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "est_boost") {
+    c->boost_opt = value ? 0 : 1;  // 1 (default) = graded response, 0 = straight to exact
   } else if (n == "lend") {
     c->lend_opt = value ? 1 : 0;
   } else if (n == "kmer_group") {
@@ -1750,6 +1766,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "chunks") *value = c->chunks;
   else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
   else if (n == "kmer_groups") *value = (int64_t)c->kgroups;
+  else if (n == "est_level") *value = c->est_ok ? (int64_t)c->est_boost : 3;  // 0..2 = boost level in use, 3 = exact
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);
@@ -2132,7 +2149,8 @@ int p3_count_short(p3_ctx* c) {
   if ((rc = do_pack(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   rc = do_count(c);
-  if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);  // estimated capacities overflowed: once more with exact offsets
+  // estimated capacities overflowed: once more at the next boost level, in the end with exact offsets
+  for (int t = 0; t < 6 && rc == P3_ERETRY_INTERNAL; t++) rc = do_count(c);
   if (rc == P3_ERETRY_INTERNAL) rc = fail(c, P3_EHIP, "internal retry failed");
   if (rc) return rc;
   HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -2197,14 +2215,14 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
   };
   rc = bloom_once();
-  if (rc == P3_ERETRY_INTERNAL) {
-    // an estimated-capacity partition overflowed: repeat with exact offsets (the count stage too if its
-    // solid-window partition was the one that overflowed; never the case under the multi-rank protocol, whose
-    // count-stage partitions are exact)
+  for (int t = 0; t < 6 && rc == P3_ERETRY_INTERNAL; t++) {
+    // an estimated-capacity partition overflowed: repeat at the next boost level / with exact offsets (the count
+    // stage too if its solid-window partition was the one that overflowed; never the case under the multi-rank
+    // protocol, whose count-stage partitions are exact)
     if (!c->counted) {
       if (c->protocol) return fail(c, P3_EHIP, "internal retry failed");
       rc = do_count(c);
-      if (rc == P3_ERETRY_INTERNAL) rc = do_count(c);
+      for (int u = 0; u < 6 && rc == P3_ERETRY_INTERNAL; u++) rc = do_count(c);
       if (rc) return rc == P3_ERETRY_INTERNAL ? fail(c, P3_EHIP, "internal retry failed") : rc;
     }
     rc = bloom_once();

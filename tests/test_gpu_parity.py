@@ -479,6 +479,7 @@ def test_skewed_keys_overflow_estimated_segments_and_retry_exactly(oracle, k):
     run_and_compare(c, oracle, (b, o), k, m, H)          # default sizing: estimated first
     assert c.get_info("count_mode") == 2 and c.get_info("bloom_mode") == 3
     assert c.get_info("est_fallbacks") >= 1               # ... and at least one stage had to fall back
+    assert c.get_info("est_level") == 3                   # ... through the boost levels to exact offsets
     keys, counts = c.export_counts()
     words = c.export_bloom()
     c.close()
@@ -487,6 +488,41 @@ def test_skewed_keys_overflow_estimated_segments_and_retry_exactly(oracle, k):
     c.load_reads(b, o, k)
     c.run_pass(k, m, H)
     assert c.get_info("est_fallbacks") == 0
+    k2, c2 = c.export_counts()
+    assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+    c.close()
+
+
+def test_mild_skew_is_absorbed_by_a_boosted_estimate(oracle):
+    """A poly-A stretch of 25 bases in 3 % of 200 k reads: ONE 21-mer with 30,000 instances, about 120 extra records
+    in each segment of its bucket (mean 100, estimated capacity 192).  The graded response repeats the stage with
+    larger estimated capacities (level 1: + 50 % of the mean, level 2: + 150 %) instead of giving the estimates up;
+    the results equal the oracle's, and the following passes run at the level that was found."""
+    k = 31
+    b, o = synth.reads(seed=41, total_reads=200000, read_len=150)
+    b = b.copy()
+    rng = np.random.default_rng(3)
+    for r in rng.choice(200000, size=6000, replace=False):
+        b[int(o[r]) + 50:int(o[r]) + 75] = ord("A")
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    run_and_compare(c, oracle, (b, o), k, m, H)
+    assert c.get_info("est_fallbacks") >= 1 and c.get_info("est_level") in (1, 2)
+    assert c.get_info("count_mode") == 2 and c.get_info("bloom_mode") == 3
+    n = c.get_info("est_fallbacks")
+    keys, counts = c.export_counts()
+    words = c.export_bloom()
+    c.run_pass(k, m, H)
+    c.run_pass(k, m, H)
+    assert c.get_info("est_fallbacks") == n            # no further overflow at the level in use
+    k2, c2 = c.export_counts()
+    assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+    c.close()
+    c = capi.Context(0)
+    c.set_option("est_boost", 0)                        # without the levels: straight to exact offsets
+    c.load_reads(b, o, k)
+    c.run_pass(k, m, H)
+    assert c.get_info("est_level") == 3
     k2, c2 = c.export_counts()
     assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
     c.close()
