@@ -98,7 +98,7 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 buffer even when device memory is plentiful (tests; default 0 = only when it is short).
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
- *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 3x -- fewer bytes to
+ *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 2x -- fewer bytes to
  *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
  *                 both forms record by record, so ranks need not agree.
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",

@@ -869,7 +869,11 @@ int agg_local(p3_ctx* c) {
   const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
   const u64 records = h[5];  // this rank's windows (left by the partition step)
   c->agg_distinct_est = distinct_est;
-  if (h[3] || (c->agg_opt != 2 && records < 3 * distinct_est)) return P3_OK;
+  // Break-even, from the one-GPU emulation of 8 ranks (tools/exp_loopback_scale.py 8 1000000 {1,2}): at 2.56
+  // records per distinct key the aggregation costs this rank 1.2 ms of kernels more per pass and takes 634 MB off
+  // what it sends.  A GPU cannot push more than 7 links x ~76 GB/s = 0.54 TB/s out (all-to-all in practice: about
+  // 0.3), i.e. those bytes cost 1.2-2.1 ms on the links: worth it from about 2 records per key, not below.
+  if (h[3] || (c->agg_opt != 2 && records < 2 * distinct_est)) return P3_OK;
   u32 sbits = 1;
   while (sbits < 5 && distinct_est / ((u64)P3_NB << sbits) > 11000) sbits++;
   for (;; sbits++) {

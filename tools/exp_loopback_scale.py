@@ -10,7 +10,7 @@ from loopback_comm import LoopbackWorld
 from bench import bloom_sizing
 
 world = int(sys.argv[1]); per = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
-agg = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+agg = int(sys.argv[3]) if len(sys.argv) > 3 else 1   # mr_aggregate: 0 raw, 1 automatic, 2 always
 k = 31
 total = per * world
 m, H = bloom_sizing(total * 150, k)
