@@ -144,6 +144,29 @@ def test_command_line_end_to_end(tmp_path_factory, tmp_path, name, materialise):
         assert "seed kmer num= %d" % case["n_seeds"] in log
 
 
+@pytest.mark.gpu
+def test_command_line_fastq_and_multiline_fasta(tmp_path_factory, tmp_path):
+    """The same reads as a FASTQ file (four lines per record) and as a FASTA file with the sequences wrapped at 60
+    columns give the reference's GFA too (row T1: both loaders feed the same ReadSet)."""
+    from test_oracle_dbg import check_against_golden, load_dbg_reads
+    name = "synth2000_k31"
+    case = [c for c in json.load(open(os.path.join(GOLDEN, "dbg_cases.json"))) if c["name"] == name][0]
+    exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
+    b, off = load_dbg_reads(name)
+    seqs = [b[int(off[i]):int(off[i + 1])].tobytes().decode() for i in range(off.size - 1)]
+    for sub, fname, text in (
+            ("fq", "reads.fastq", "".join("@r%d\n%s\n+\n%s\n" % (i, q, "I" * len(q)) for i, q in enumerate(seqs))),
+            ("wrapped", "reads.fasta", "".join(">r%d\n%s\n" % (i, "\n".join(q[j:j + 60] for j in range(0, len(q), 60)))
+                                               for i, q in enumerate(seqs)))):
+        wd = os.path.join(str(tmp_path), sub)
+        os.makedirs(wd)
+        with open(os.path.join(wd, fname), "w") as f:
+            f.write(text)
+        args = [exe, "-i", os.path.join(wd, fname), "-k", str(case["k"]), "-t", "1"] + (["-m", str(case["m"])] if case["H"] == 10 else [])
+        subprocess.check_call(args, cwd=wd, timeout=180)
+        check_against_golden(case, open(os.path.join(wd, "de_bruijn_graph.gfa")).read())
+
+
 def test_command_line_without_input_prints_usage(tmp_path_factory, tmp_path):
     exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
     r = subprocess.run([exe], capture_output=True, cwd=str(tmp_path), timeout=60)
