@@ -12,6 +12,9 @@ b, o = synth.reads(seed=3, total_reads=R, read_len=L, sub_rate_ppm=ppm)
 m, H = bloom_sizing(int(b.size), k)
 print("%d x %d bp = %.2f G bases, m=%d H=%d (synth %.1f s)" % (R, L, b.size / 1e9, m, H, time.time() - t0), flush=True)
 c = capi.Context(0)
+for kv in os.environ.get("P3_OPTS", "").split(","):   # e.g. P3_OPTS=kmer_split=3,kmer_collect=0
+    if kv:
+        c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 t0 = time.time(); c.load_reads(b, o, k); print("load %.1f s" % (time.time() - t0), flush=True)
 for i in range(int(os.environ.get('P3_PASSES', '2'))):
     t0 = time.perf_counter(); c.run_pass(k, m, H); dt = time.perf_counter() - t0
