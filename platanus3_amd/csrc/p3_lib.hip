@@ -176,6 +176,8 @@ int fail(p3_ctx* c, int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   if (c) c->err = buf;
+  static const bool trace = getenv("P3_TRACE_ERR") != nullptr;  // diagnostic: every failure, internal retries included
+  if (trace) fprintf(stderr, "[p3] status %d: %s\n", code, buf);
   return code;
 }
 
@@ -1229,8 +1231,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       // the split that worked for the previous pass over the same reads and k is the best first guess
       if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k) {
         if (c->kxg) {
-          kxg = c->kxg;
-          sbits = 0;
+          // (the split form needs estimated capacities: an attempt whose estimate overflowed has already noted its
+          // kxg here, and the exact repeat must not pick it up again)
+          if (est) {
+            kxg = c->kxg;
+            sbits = 0;
+          }
         } else if (c->ksbits > sbits && c->ksbits <= 5) {
           sbits = c->ksbits;
         }
@@ -1240,7 +1246,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         kxg = 1;
         while (kxg < 10 && (c->dall_n >> kxg) / P3_NB > ((u64)4 << ts_log2)) kxg++;
       }
-      if (c->ksplit_opt >= 2) {  // tests: force the split form
+      if (c->ksplit_opt >= 2 && est) {  // tests: force the split form (it only exists with estimated capacities)
         kxg = (u32)c->ksplit_opt - 1;
         sbits = 0;
       }
@@ -1382,7 +1388,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     est_overflowed(c);
     c->counted = c->counted && !hall[26];
-    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded (Bloom stage: k-mer/probe partition %llu, count stage %llu; level now %u%s)",
+                (unsigned long long)hall[25], (unsigned long long)hall[26], c->est_boost, c->est_ok ? "" : ", exact next");
   }
   if (c->spec) {
     // the single synchronisation point of a speculative pass: were last pass's splits still good?

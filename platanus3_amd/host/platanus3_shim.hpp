@@ -228,12 +228,24 @@ class ReadFile {
   // the end of the text commits whatever is pending, whatever its name (:72-75,:99-102).
   void parse(const std::string& text, ReadSet* dst, bool fastq) {
     std::string pending_name, pending_seq;
-    auto commit = [&]() {
+    auto commit = [&]() {  // (every commit is followed by pending_seq.clear() or by the end of the parse: move)
       if (pending_seq.size() >= large_kmer_length) {
-        (*dst)[pending_name] = pending_seq;
         all_bases += pending_seq.size();
+        (*dst)[pending_name] = std::move(pending_seq);
+        pending_seq.clear();
       }
     };
+    {  // one bucket array for the whole file instead of ~20 rehashes: records = header lines
+      size_t records = 0;
+      if (fastq) {
+        for (const char* q = text.data(), *e = q + text.size(); (q = (const char*)std::memchr(q, '\n', (size_t)(e - q))); q++) records++;
+        records = records / 4 + 1;
+      } else {
+        for (size_t q = 0; q < text.size(); q = text.find('\n', q), q = (q == std::string::npos ? text.size() : q + 1))
+          records += text[q] == '>';
+      }
+      dst->reserve(dst->size() + records);
+    }
     size_t pos = 0, line_no = 0;
     while (pos < text.size()) {  // getline semantics: a final line without '\n' counts, a final '\n' adds no line
       size_t eol = text.find('\n', pos);

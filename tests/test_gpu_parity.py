@@ -649,3 +649,68 @@ def test_kmer_second_level_partition(oracle, split, k):
     c.k = k
     assert seeds_as_strings(c) == eseeds
     c.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_configurations(oracle, seed):
+    """Randomised sweep over input shapes AND path options: every combination must equal the oracle, on the first
+    pass and on a repeated (speculative) one.  Inputs: ragged read lengths (some shorter than k, unknown characters,
+    lowercase) or fixed-length synthetic reads; k anywhere in [21,64]; Bloom sizes from a few hundred bits to the
+    estimated size; H in [1,24].  Options: forced position chunks, second-level partitions of both stages, LDS table
+    sizes that force sub-bucket splits, both gates, exact / estimated sizing, slices on / off, collection and lending."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(6):
+        k = int(rng.integers(21, 65))
+        if rng.random() < 0.5:
+            reads = random_reads(rng, int(rng.integers(1, 2500)), lo=int(rng.integers(1, 40)), hi=int(rng.integers(60, 500)),
+                                 genome_len=int(rng.integers(500, 30000)))
+            b, o = flat(reads)
+        else:
+            b, o = synth.reads(seed=int(rng.integers(1, 1 << 30)), total_reads=int(rng.integers(50, 6000)),
+                               read_len=int(rng.integers(k + 1, 400)), sub_rate_ppm=int(rng.choice([0, 5000, 30000])))
+        lens = np.diff(o.astype(np.int64))
+        all_bases = int(lens[lens >= k].sum())
+        if rng.random() < 0.5 and all_bases > 0:
+            m, H = oracle.estimate_bloom(all_bases, k)
+            if m == 0:
+                m, H = 1009, 3
+        else:
+            m, H = int(rng.choice([257, 4099, 65537, 1 << 20, (1 << 22) + 3])), int(rng.integers(1, 25))
+        opts = {}
+        if rng.random() < 0.4:
+            opts["chunks"] = int(rng.choice([2, 4, 8]))
+            opts["kmer_collect"] = int(rng.choice([0, 1, 2]))
+            opts["lend"] = int(rng.integers(0, 2))
+            opts["kmer_group"] = int(rng.choice([0, 2, 3]))
+        if rng.random() < 0.3:
+            opts["count_split"] = int(rng.choice([1, 2, 3, 4]))
+        if rng.random() < 0.3:
+            opts["kmer_split"] = int(rng.choice([2, 3, 5]))
+        if rng.random() < 0.3:
+            opts["ts_log2"] = int(rng.choice([6, 8, 10]))
+        if rng.random() < 0.3:
+            opts["tsk_log2"] = int(rng.choice([6, 8, 10]))
+        if rng.random() < 0.3:
+            opts["gate_mode"] = int(rng.choice([1, 2]))
+        if rng.random() < 0.2:
+            opts["part_sizing"] = 1
+        if rng.random() < 0.2:
+            opts["bloom_slices"] = 0
+        if rng.random() < 0.2:
+            opts["est_boost"] = 0
+        c = capi.Context(0)
+        try:
+            for name, v in opts.items():
+                c.set_option(name, v)
+            words, _ = run_and_compare(c, oracle, (b, o), k, m, H)
+            keys, counts = c.export_counts()
+            c.run_pass(k, m, H)
+            c.run_pass(k, m, H)
+            k2, c2 = c.export_counts()
+            assert np.array_equal(keys, k2) and np.array_equal(counts, c2), (seed, case, k, m, H, opts)
+            assert np.array_equal(words, c.export_bloom()), (seed, case, k, m, H, opts)
+        except Exception as e:
+            raise AssertionError("seed %d case %d: k=%d m=%d H=%d reads=%d opts=%r: %s: %s" %
+                                 (seed, case, k, m, H, o.size - 1, opts, type(e).__name__, e))
+        finally:
+            c.close()
