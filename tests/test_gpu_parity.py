@@ -714,3 +714,133 @@ def test_random_configurations(oracle, seed):
                                  (seed, case, k, m, H, o.size - 1, opts, type(e).__name__, e))
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_multirank_random_configurations(oracle, seed):
+    """Randomised sweep of the multi-rank protocol with the real kernels (N contexts on one GPU, loopback exchange):
+    world size, k, read shapes (ragged reads shorter than k included), Bloom size, gate form, per-rank aggregation
+    choice and table / split options.  Two passes; the union of the shards equals the oracle on all reads."""
+    import threading
+    from loopback_comm import LoopbackWorld
+    from platanus3_amd.pipeline import Pipeline
+    rng = np.random.default_rng(5000 + seed)
+    world = int(rng.choice([2, 4, 8]))
+    k = int(rng.integers(21, 65))
+    if rng.random() < 0.5:
+        reads = random_reads(rng, int(rng.integers(world, 4000)), lo=int(rng.integers(1, 40)), hi=int(rng.integers(60, 400)),
+                             genome_len=int(rng.integers(500, 30000)))
+        b, o = flat(reads)
+    else:
+        b, o = synth.reads(seed=int(rng.integers(1, 1 << 30)), total_reads=int(rng.integers(world, 12000)),
+                           read_len=int(rng.integers(k + 1, 300)), sub_rate_ppm=int(rng.choice([0, 5000, 30000])))
+    n_reads = (o.size - 1) // world * world
+    per = n_reads // world
+    b, o = b[:max(1, int(o[n_reads]))], o[:n_reads + 1]
+    lens = np.diff(o.astype(np.int64))
+    all_bases = int(lens[lens >= k].sum())
+    if rng.random() < 0.5 and all_bases > 0:
+        m, H = oracle.estimate_bloom(all_bases, k)
+        if m == 0:
+            m, H = 1009, 3
+    else:
+        m, H = int(rng.choice([257, 4099, 65537, 1 << 20, (1 << 22) + 3])), int(rng.integers(1, 25))
+    common = {"gate_mode": int(rng.choice([1, 2]))}
+    if rng.random() < 0.3:
+        common["count_split"] = int(rng.choice([1, 2, 3]))
+    if rng.random() < 0.3:
+        common["ts_log2"] = int(rng.choice([6, 8, 10]))
+    per_rank = [{"mr_aggregate": int(rng.choice([0, 1, 2])),
+                 **({"tsk_log2": int(rng.choice([6, 8, 10]))} if rng.random() < 0.3 else {}),
+                 **({"kmer_split": int(rng.choice([2, 3]))} if rng.random() < 0.3 else {}),
+                 **({"bloom_slices": 0} if rng.random() < 0.2 else {})} for _ in range(world)]
+    what = "seed %d: world=%d k=%d m=%d H=%d reads=%d common=%r per_rank=%r" % (seed, world, k, m, H, n_reads, common, per_rank)
+    lw = LoopbackWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            bb = b[int(o[r * per]):max(int(o[(r + 1) * per]), int(o[r * per]) + 1)]
+            oo = o[r * per:(r + 1) * per + 1] - o[r * per]
+            pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
+            for name, v in {**common, **per_rank[r]}.items():
+                pipe.ctx.set_option(name, v)
+            pipe.load_reads(bb, oo, min_len=k)
+            pipe.run_pass(k, m, H)
+            pipe.run_pass(k, m, H)
+            c = pipe.ctx
+            c.k, c.m, c.H = k, m, H
+            keys, counts = c.export_counts()
+            results[r] = (keys.copy(), counts.copy(), c.export_bloom(), [capi.decode_key(x, k) for x in c.export_seeds()])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, (what, errors)
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    keys = np.concatenate([r[0] for r in results])
+    counts = np.concatenate([r[1] for r in results])
+    assert np.unique(keys).size == keys.size, what
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], ekeys) and np.array_equal(counts[order], ecounts), what
+    for r in results:
+        assert np.array_equal(r[2], ebloom), what
+    assert sorted(set(s for r in results for s in r[3])) == eseeds, what
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_configurations_medium(oracle, seed):
+    """The same sweep at 50-250 k reads (segment means of 25-130 records, LDS tables that really fill): forced chunks,
+    splits, small tables, skew (a poly-A stretch in some reads) -- against the oracle, two more passes after the first."""
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([21, 25, 31, 33, 41, 55, 63]))
+    L = int(rng.choice([100, 150, 250]))
+    n = int(rng.integers(50_000, 250_000) * 150 // L)
+    b, o = synth.reads(seed=int(rng.integers(1, 1 << 30)), total_reads=n, read_len=L, sub_rate_ppm=int(rng.choice([1000, 5000, 20000])))
+    if rng.random() < 0.4:
+        b = b.copy()
+        for r in rng.choice(n, size=int(n * rng.choice([0.005, 0.03])), replace=False):
+            b[int(o[r]) + 30:int(o[r]) + 30 + int(rng.integers(22, 60))] = ord("A")
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    if rng.random() < 0.3:
+        m, H = int(rng.choice([(1 << 24) + 7, 1 << 27])), 10
+    opts = {}
+    if rng.random() < 0.5:
+        opts["chunks"] = int(rng.choice([2, 4, 8, 16]))
+        opts["kmer_collect"] = int(rng.choice([0, 1, 2]))
+        opts["lend"] = int(rng.integers(0, 2))
+        opts["kmer_group"] = int(rng.choice([0, 2, 3]))
+    if rng.random() < 0.4:
+        opts["count_split"] = int(rng.choice([1, 2, 3, 5]))
+    if rng.random() < 0.4:
+        opts["kmer_split"] = int(rng.choice([2, 3, 5]))
+    if rng.random() < 0.4:
+        opts["ts_log2"] = int(rng.choice([8, 10, 12]))
+    if rng.random() < 0.4:
+        opts["tsk_log2"] = int(rng.choice([8, 10, 12]))
+    if rng.random() < 0.2:
+        opts["gate_mode"] = 1
+    if rng.random() < 0.15:
+        opts["bloom_slices"] = 0
+    what = "seed %d: k=%d L=%d reads=%d m=%d H=%d opts=%r" % (seed, k, L, n, m, H, opts)
+    c = capi.Context(0)
+    try:
+        for name, v in opts.items():
+            c.set_option(name, v)
+        words, _ = run_and_compare(c, oracle, (b, o), k, m, H)
+        keys, counts = c.export_counts()
+        c.run_pass(k, m, H)
+        c.run_pass(k, m, H)
+        k2, c2 = c.export_counts()
+        assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+    except Exception as e:
+        raise AssertionError("%s: %s: %s" % (what, type(e).__name__, e))
+    finally:
+        c.close()
