@@ -438,8 +438,14 @@ u32 segcap_for(const p3_ctx* c, double mean) {
 // an estimated-capacity segment overflowed: next boost level, or no more estimates for these reads
 void est_overflowed(p3_ctx* c) {
   c->est_fallbacks++;
-  // (beyond 2^31 positions the partitions are tens of GB: one level only)
-  const u32 top = (c->n_words_all ? c->n_words_all : c->n_words) * 32 > (1ull << 31) ? 1u : 2u;
+  // (large inputs: the position partition is 8 B per window, 2.5x that at level 2 -- only while it stays within a
+  // third of the device memory, 33 M reads of 150 bp on 288 GB)
+  const u64 positions = (c->n_words_all ? c->n_words_all : c->n_words) * 32;
+  size_t mem_free = 0, mem_total = 0;
+  u32 top = 2;
+  if (positions > (1ull << 31) &&
+      (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || (double)positions * 8.0 * 2.5 > 0.35 * (double)mem_total))
+    top = 1;
   if (c->est_boost < top && c->boost_opt != 1) c->est_boost++;
   else c->est_ok = false;
 }
@@ -1091,12 +1097,17 @@ int do_count(p3_ctx* c) {
   c->chunks = 1;
   const u32 nch = chunks_for(c);
   if (nch) {
-    bool ovf = false;
-    rc = do_count_chunked(c, nch, &ovf);
-    if (rc == P3_OK && !ovf) return P3_OK;
-    c->chunks = 1;
-    if (rc != P3_OK && rc != P3_ERETRY_INTERNAL) return rc;
-    // an estimate overflowed or a table did at every split: the direct kernels below take over
+    for (;;) {
+      bool ovf = false;
+      rc = do_count_chunked(c, nch, &ovf);
+      if (rc == P3_OK && !ovf) return P3_OK;
+      c->chunks = 1;
+      if (rc != P3_OK && rc != P3_ERETRY_INTERNAL) return rc;
+      // an estimate overflowed: once more at the next boost level while there is one (mild skew); then, or when a
+      // table overflowed at every split, the direct kernels below take over
+      if (rc == P3_ERETRY_INTERNAL && chunks_for(c) == nch) continue;
+      break;
+    }
   }
   const bool can_part = part_applicable(c) && !nch;
   if (c->count_mode_opt == 2 && !can_part) return fail(c, P3_EBADARG, "partitioned count forced but input too large");

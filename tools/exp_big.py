@@ -9,6 +9,12 @@ L = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 ppm = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
 t0 = time.time()
 b, o = synth.reads(seed=3, total_reads=R, read_len=L, sub_rate_ppm=ppm)
+skew = float(os.environ.get("P3_SKEW", "0"))   # fraction of the reads that get a 25-base poly-A stretch (skewed keys)
+if skew > 0:
+    import numpy as np
+    starts = o[:-1][np.random.default_rng(1).choice(R, size=int(R * skew), replace=False)].astype(np.int64) + 40
+    idx = (starts[:, None] + np.arange(25)[None, :]).ravel()
+    b[idx] = ord("A")
 m, H = bloom_sizing(int(b.size), k)
 print("%d x %d bp = %.2f G bases, m=%d H=%d (synth %.1f s)" % (R, L, b.size / 1e9, m, H, time.time() - t0), flush=True)
 c = capi.Context(0)
@@ -23,7 +29,7 @@ for i in range(int(os.environ.get('P3_PASSES', '2'))):
           (i, c.timings()["ms_total"], dt * 1e3, nk / dt / 1e9, c.get_info("chunks"), c.get_info("split_xbits"), c.get_info("count_mode"), c.get_info("bloom_mode")), flush=True)
     import ctypes as _C
     c.L.p3_last_error.restype = _C.c_char_p
-    print("   est_fallbacks=%d ksplit_xbits=%d ksbits=%d last_error=%r" % (c.get_info("est_fallbacks"), c.get_info("ksplit_xbits"), c.get_info("ksbits"), c.L.p3_last_error(c.h)), flush=True)
+    print("   est_fallbacks=%d est_level=%d ksplit_xbits=%d ksbits=%d kmer_groups=%d last_error=%r" % (c.get_info("est_fallbacks"), c.get_info("est_level"), c.get_info("ksplit_xbits"), c.get_info("ksbits"), c.get_info("kmer_groups"), c.L.p3_last_error(c.h)), flush=True)
 print(c.count_stats(), c.bloom_stats(), flush=True)
 assert c.count_stats()["n_windows"] == R * (L - 20)
 c.reset_kernel_stats(); c.set_profiling(True); c.run_pass(k, m, H); c.set_profiling(False)
