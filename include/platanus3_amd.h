@@ -94,6 +94,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "est_boost"   1 (default) = an overflowing estimated-capacity partition (skewed keys) is repeated with larger
  *                 estimated capacities (+50 %, then +150 % of the mean) before exact offsets are used; 0 = straight to
  *                 exact offsets.  p3_get_info "est_level" reads back 0..2 (level in use) or 3 (exact).
+ *   "var_caps"    1 (default) = from the first overflow on, the second-level partitions (k_split) size every cell from a
+ *                 sample of their input, so that a cell holding a heavy key (poly-A, satellites) gets the room it
+ *                 needs; 0 = uniform capacities only (tests).
  *   "lend"        position chunks: 1 = the Bloom stage's scratch buffers are carved from the count stage's partition
  *                 buffer even when device memory is plentiful (tests; default 0 = only when it is short).
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer

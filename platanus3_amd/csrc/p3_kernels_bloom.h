@@ -55,13 +55,21 @@ __device__ __forceinline__ u64 khash(u64 lo, u64 hi) {  // bits 63..54 = bucket,
 // capacity (mean + 6 sigma + slack, a multiple of 16 records) at a fixed stride -- no histogram pass, no scan;
 // the scatter kernel reports the exact per-segment counts it wrote (ghist_out) and raises *ovf if a segment did
 // not fit (skewed input), in which case the host repeats the stage in exact mode.
+// Variable mode (caps != nullptr, segcap == P3_VCAP; k_split after an overflow): every ROW has its own capacity
+// caps[b] -- sized from a sample of the input (k_cell_sample / k_var_caps), so that a cell holding a heavy key gets
+// the room it needs -- and explicit segment offsets (seg_off).  The stager needs no extra state for it: the write
+// position of row b starts at P3_VCAP - caps[b] and its base is lowered by the same amount (u32 wrap-around), so the
+// common "position + chunk > segcap" test is the per-row test.
+#define P3_VCAP (1u << 30)
 struct EstSeg {
   u32 segcap;
   u32* ghist_out;
   u64* ovf;
+  const u32* caps;
 };
 
 __device__ __forceinline__ u32 seg_base(const u32* __restrict__ seg_off, u32 bucket, const EstSeg& est) {
+  if (est.caps) return seg_off[bucket * P3_NWG + blockIdx.x] - (P3_VCAP - est.caps[bucket]);
   return est.segcap ? (bucket * P3_NWG + blockIdx.x) * est.segcap : seg_off[bucket * P3_NWG + blockIdx.x];
 }
 
@@ -139,7 +147,7 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
         // host has seen the flag (single-synchronisation passes) stays inside the segment
         if (q == 0) *est.ovf = 1;
       } else {
-        uint4* dst = reinterpret_cast<uint4*>(out + s.segb[b] + wp);
+        uint4* dst = reinterpret_cast<uint4*>(out + (u32)(s.segb[b] + wp));  // (u32 sum: variable mode wraps)
         const uint4* row = s.rows + b * 8;
         dst[q] = row[par * 4 + q];
         if (nch == 2) dst[4 + q] = row[(par ^ 1u) * 4 + q];
@@ -152,7 +160,8 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
   }
   if (final_flush && est.segcap) {
     const u32 tot = s.wpos[t] + n0;  // (a final partial chunk that did not fit was not written either)
-    est.ghist_out[t * P3_NWG + blockIdx.x] = tot <= est.segcap ? tot : s.wpos[t];
+    const u32 bias = est.caps ? P3_VCAP - est.caps[t] : 0u;
+    est.ghist_out[t * P3_NWG + blockIdx.x] = (tot <= est.segcap ? tot : s.wpos[t]) - bias;
   }
 }
 
@@ -273,7 +282,7 @@ __device__ __forceinline__ void stage_run(const StageLds& s, REC* __restrict__ o
 __device__ __forceinline__ void stage_init(const StageLds& s, const u32* seg_off, const EstSeg est) {
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
     s.cnt[i] = 0;
-    s.wpos[i] = 0;
+    s.wpos[i] = est.caps ? P3_VCAP - est.caps[i] : 0u;
     s.segb[i] = seg_base(seg_off, i, est);
   }
   if (threadIdx.x < 2) s.flag[threadIdx.x] = 0;

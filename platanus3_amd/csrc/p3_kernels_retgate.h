@@ -304,7 +304,8 @@ template <typename REC, int KIND>
 __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
                                                           const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
                                                           u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
-                                                          REC* __restrict__ out, EstSeg est) {
+                                                          REC* __restrict__ out, EstSeg est,
+                                                          const u32* __restrict__ out_segoff = nullptr) {
   constexpr u32 RPV = 16 / sizeof(REC);  // records per 16-byte vector
   constexpr int N = 2 * (int)RPV;        // records per lane and step (two vectors)
   extern __shared__ __align__(16) u32 lds[];
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict
   u32* item_off = lds + P3_STAGE_WORDS;  // [rows * n_src] first record of the item (relative to the source's data)
   u32* item_cnt = item_off + P3_NB;      // [rows * n_src] records
   u32* s_maxsteps = item_cnt + P3_NB;
-  stage_init(stg, nullptr, est);
+  stage_init(stg, out_segoff, est);  // (out_segoff: variable per-cell capacities, see EstSeg::caps)
   const u32 wps = P3_NWG / n_src;  // workgroups per source
   const u32 src = blockIdx.x / wps, j0 = blockIdx.x % wps;
   const u32 n_items = rows * n_src;  // <= 1024
@@ -390,4 +391,98 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict
     }
     return true;
   });
+}
+
+// ---- variable per-cell capacities for k_split (used once an estimated capacity has overflowed) -----------------------
+// A key with hundreds of thousands of instances (poly-A, satellites) puts all of them into ONE of a group's 1024
+// cells; no uniform capacity short of the worst case holds that.  k_cell_sample counts every 64th 16-byte vector of
+// the group's input by cell (same items per workgroup and same cell function as k_split), k_var_caps turns the counts
+// into a capacity per cell -- the uniform one, or what the sample predicts for the cell plus its 6 sigma -- lays the
+// segments out and leaves the table of capacities for the stager (EstSeg::caps).  Nothing is read back by the host.
+template <typename REC, int KIND>
+__global__ void __launch_bounds__(P3_PART_THREADS) k_cell_sample(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
+                                                                const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
+                                                                u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
+                                                                u32* __restrict__ cellcnt) {
+  constexpr u32 RPV = 16 / sizeof(REC);
+  __shared__ u32 hist[P3_NB];
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const u32 wps = P3_NWG / n_src;
+  const u32 src = blockIdx.x / wps, j0 = blockIdx.x % wps;
+  const u32 n_items = rows * n_src;
+  const REC* data = in + roff[src] - in_segoff[(u64)src * desc_rows * P3_NWG];
+  const u32 cmask = (1u << xbits) - 1u;
+  if (threadIdx.x < n_items) {
+    const u32 i = threadIdx.x, r = i / n_src, t = i % n_src;
+    const u64 d = ((u64)src * desc_rows + first_row + r) * P3_NWG + j0 + t * wps;
+    const u32 off = in_segoff[d], cnt = in_ghist[d];
+    const uint4* vecs = reinterpret_cast<const uint4*>(data + off);
+    const u32 rbase = r << xbits;
+    for (u32 v = (i * 13u) & 63u; v * RPV < cnt; v += 64) {
+      const uint4 q = vecs[v];
+      if constexpr (KIND == 2) {
+        const u64 lo = ((u64)q.y << 32) | q.x, hi = ((u64)q.w << 32) | q.z;
+        atomicAdd(&hist[rbase | (((kfold<2>(lo, hi) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask)], 1u);
+      } else {
+        const u64 r0 = ((u64)q.y << 32) | q.x, r1 = ((u64)q.w << 32) | q.z;
+        u32 c0, c1;
+        if constexpr (KIND == 0) {
+          c0 = rbase | (q.x >> (32 - xbits));
+          c1 = rbase | (q.z >> (32 - xbits));
+        } else {
+          c0 = rbase | (((kfold<1>(r0, 0) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask);
+          c1 = rbase | (((kfold<1>(r1, 0) * 0x9E3779B1u) >> (32 - P3_PBITS - xbits)) & cmask);
+        }
+        atomicAdd(&hist[c0], 1u);
+        if (v * 2 + 1 < cnt) atomicAdd(&hist[c1], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x)
+    if (hist[i]) atomicAdd(&cellcnt[i], hist[i]);
+}
+
+// one workgroup of P3_NB threads.  seg_scale = 64 (sampling) x margin / P3_NWG: sampled records of a cell -> expected
+// records of one of its segments; boost_mul = extra factor on that (1: the sample already sees the skew); cap_records = records the output
+// buffer holds (*flag is raised when the capacities do not fit it).  cellcnt is left zeroed for the next group.
+__global__ void __launch_bounds__(P3_NB) k_var_caps(u32* __restrict__ cellcnt, float seg_scale, float boost_mul, u32 uniform_cap,
+                                                    u64 cap_records, u32* __restrict__ caps, u32* __restrict__ seg_off,
+                                                    u64* __restrict__ flag) {
+  __shared__ u64 base[P3_NB];
+  __shared__ u32 cap_s[P3_NB];
+  const u32 t = threadIdx.x;
+  const float smp = (float)cellcnt[t];
+  // expected records of one segment, plus three sigma of the sampling itself (1 / sqrt(samples) relative)
+  const float e = smp * seg_scale * (1.0f + 3.0f * rsqrtf(smp > 1.0f ? smp : 1.0f));
+  cellcnt[t] = 0;
+  u32 cap = (u32)(e * boost_mul + 6.0f * sqrtf(e) + 32.0f);
+  cap = (cap + 15u) & ~15u;
+  if (cap < uniform_cap) cap = uniform_cap;
+  cap_s[t] = cap;
+  caps[t] = cap;
+  base[t] = (u64)cap * P3_NWG;
+  __syncthreads();
+  for (u32 d = 1; d < P3_NB; d <<= 1) {  // inclusive scan
+    const u64 v = t >= d ? base[t - d] : 0;
+    __syncthreads();
+    base[t] += v;
+    __syncthreads();
+  }
+  const u64 total = base[P3_NB - 1];
+  __syncthreads();
+  if (total > cap_records || total >= (1ull << 32)) {  // (uniform over the workgroup)
+    if (t == 0) *flag = 1;
+    // keep the layout inside the buffer: uniform capacities (the stager then reports the overflow as usual)
+    cap_s[t] = uniform_cap;
+    caps[t] = uniform_cap;
+    __syncthreads();
+    base[t] = (u64)(t + 1) * uniform_cap * P3_NWG;
+  }
+  __syncthreads();
+  for (u32 i = t; i < P3_NB * P3_NWG; i += P3_NB) {
+    const u32 c = i / P3_NWG, w = i % P3_NWG;
+    seg_off[i] = (u32)(base[c] - (u64)cap_s[c] * P3_NWG) + w * cap_s[c];
+  }
 }

@@ -76,6 +76,7 @@ struct p3_ctx {
   int tsk_log2_opt = 14;
   int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)
   int sizing_opt = 0;       // 0 auto (estimated segment capacities on one rank), 1 exact (histogram + scan)
+  bool chunk_ok = true;     // cleared when the position-chunk form failed even with exact first-level offsets
   u32 est_boost = 0;        // skew response: 0 / 1 / 2 = segment capacities of the estimate + 0 / 50 / 150 % of the mean
   bool est_ok = true;       // cleared when an estimated segment overflowed at the last boost level (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0, ksbits_k = 0;
@@ -100,6 +101,8 @@ struct p3_ctx {
   bool chunk_acc = false;    // do_bloom_t: later chunk (keep the Bloom vector, OR into it), no seeds yet
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
+  DevBuf cellcnt, caps;  // k_split with per-cell capacities (after an overflow): sampled counts, capacities
+  int varcap_opt = 1;    // tests: 0 = never use per-cell capacities
   // chunked Bloom stage under memory pressure: the count stage's partition buffer is lent to the k-mer stage's
   // scratch buffers (kpart, klpart, dkeys, dall, ppart) instead of being freed (LendScope)
   char* arena_p = nullptr;
@@ -359,6 +362,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->reads_epoch++;
   c->hint_valid = false;
   c->est_ok = true;
+  c->chunk_ok = true;
   c->est_boost = 0;
   c->kcollect_ok = true;
   c->distinct_cap = 0;
@@ -438,6 +442,7 @@ u32 segcap_for(const p3_ctx* c, double mean) {
 // an estimated-capacity segment overflowed: next boost level, or no more estimates for these reads
 void est_overflowed(p3_ctx* c) {
   c->est_fallbacks++;
+  if (!c->est_ok) c->chunk_ok = false;  // (already on exact first-level offsets: a second-level partition overflowed)
   // (large inputs: the position partition is 8 B per window, 2.5x that at level 2 -- only while it stays within a
   // third of the device memory, 33 M reads of 150 bp on 288 GB)
   const u64 positions = (c->n_words_all ? c->n_words_all : c->n_words) * 32;
@@ -559,6 +564,18 @@ int repartition_rx(p3_ctx* c) {
 }
 
 int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb);
+
+// k_split with per-cell capacities (k_cell_sample / k_var_caps): from the first overflow of an estimate on
+bool var_caps_on(const p3_ctx* c) { return c->est_boost >= 1 && c->varcap_opt != 0; }
+float var_seg_scale() { return 64.0f * 1.15f / (float)P3_NWG; }  // sampled vectors of a cell -> records of one segment, + 15 %
+float var_boost_mul(const p3_ctx*) { return 1.0f; }  // (the uniform capacity, the lower bound of every cell, carries the level's boost)
+int var_caps_prepare(p3_ctx* c) {
+  int rc;
+  if ((rc = ensure(c, c->cellcnt, (size_t)P3_NB * 4))) return rc;
+  if ((rc = ensure(c, c->caps, (size_t)P3_NB * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->cellcnt.p, 0, (size_t)P3_NB * 4, c->stream));
+  return P3_OK;
+}
 
 // the count kernel's two rarely used inputs (see k_part_count): dstats[30] = entries its table outputs hold,
 // sing_cursor[P3_MAX_RANKS + s] = start of source s's list in `singles` (copied from the device table `sroff`, n of them)
@@ -697,6 +714,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 31, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
   const u32 ts_log2 = (u32)c->ts_log2_opt;
   if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
@@ -707,14 +725,31 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const double total = (mr || chunked) ? (double)c->rx_records * 1.02
                                        : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
   const u32 segcap = segcap_for(c, total / ((double)groups * P3_NB * P3_NWG));
-  if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
-  LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
+  // once an estimate has overflowed for these reads (level >= 1), every cell gets its own capacity from a sample of
+  // the group's input (a heavy key fills ONE cell): a quarter more room than the uniform layout, shared by need
+  const bool var = var_caps_on(c);
+  const u64 cap_records = (u64)P3_NB * P3_NWG * segcap + (var ? (u64)P3_NB * P3_NWG * segcap / 4 : 0);
+  if ((rc = ensure(c, c->lpart, cap_records * 8))) return rc;
+  if (var) {
+    if ((rc = var_caps_prepare(c))) return rc;
+  } else {
+    LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
+  }
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
   for (u32 g = 0; g < groups; g++) {
+    if (var) {
+      LAUNCH(c, "k_cell_sample", (k_cell_sample<u64, 0>), P3_NWG, P3_PART_THREADS, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
+             (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, mr ? rows_total : (u32)P3_NB, g * rows, rows, xbits,
+             (u32*)c->cellcnt.p);
+      LAUNCH(c, "k_var_caps", k_var_caps, 1, P3_NB, (u32*)c->cellcnt.p, var_seg_scale(), var_boost_mul(c), segcap, cap_records,
+             (u32*)c->caps.p, (u32*)c->seg_off2.p, st + 27);
+    }
     LAUNCH_LDS(c, "k_split", (k_split<u64, 0>), P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
                (const u32*)c->rx_ghist, (const u64*)c->rx_roff.p, n_src, mr ? rows_total : (u32)P3_NB, g * rows, rows, xbits,
-               (u64*)c->lpart.p, (EstSeg{segcap, (u32*)c->ghist2.p, st + 26}));
+               (u64*)c->lpart.p,
+               (EstSeg{var ? P3_VCAP : segcap, (u32*)c->ghist2.p, st + 26, var ? (const u32*)c->caps.p : nullptr}),
+               var ? (const u32*)c->seg_off2.p : nullptr);
     if (n_src > 1) {  // (xbits >= log2 n_src by construction)
       LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
@@ -738,9 +773,10 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   u64 h[32];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (h[26]) {
+  if (h[26] || h[27]) {
     est_overflowed(c);
-    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded (second-level partition of the count stage: segment %llu, sampled layout %llu; per-cell capacities %s)",
+                (unsigned long long)h[26], (unsigned long long)h[27], var_caps_on(c) ? "on" : "off");
   }
   if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
     c->distinct_cap = maxd * 2;
@@ -986,7 +1022,10 @@ struct ChunkView {
 };
 
 u32 chunks_for(const p3_ctx* c) {  // 0 = the chunked form does not apply
-  if (c->chunk_opt == 1 || c->n_ranks != 1 || c->protocol || !c->est_ok || c->sizing_opt == 1) return 0;
+  // (est_ok false = heavy skew: the chunks' first-level partitions then use exact offsets, the second-level ones
+  // sampled per-cell capacities; only when that fails too -- chunk_ok -- do the direct kernels take over)
+  if (c->chunk_opt == 1 || c->n_ranks != 1 || c->protocol || !c->chunk_ok || c->sizing_opt == 1) return 0;
+  if (!c->est_ok && !var_caps_on(c)) return 0;
   if (c->count_mode_opt == 1 || c->gate_mode_opt == 1 || c->bloom_mode_opt == 1) return 0;
   const u64 pos = c->n_words * 32;
   if (c->chunk_opt >= 2) return (pos / (u32)c->chunk_opt <= (1ull << 30)) ? (u32)c->chunk_opt : 0;
@@ -1009,7 +1048,8 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   u64 per = (wc + P3_NWG - 1) / P3_NWG;
   per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
   const double mean21 = hw0 > 0 ? (hw0 + 1) * 1.02 / ((double)P3_NB * active_wgs(wc)) : (double)(per * 32) / P3_NB;
-  const u64 region = (u64)P3_NB * P3_NWG * (segcap_for(c, mean21) + 16);  // records per chunk partition (a little slack)
+  // records per chunk partition: estimated capacities (a little slack), or what exact offsets can need at most
+  const u64 region = est_mode(c) ? (u64)P3_NB * P3_NWG * (segcap_for(c, mean21) + 16) : wc * 32 + 16ull * P3_NWG * P3_NB;
   const size_t desc = (size_t)P3_NB * P3_NWG * 4;
   if ((rc = ensure(c, c->part8c, (u64)C * region * 8))) return rc;
   if ((rc = ensure(c, c->rx_ghist_buf, (size_t)C * desc))) return rc;
@@ -1025,7 +1065,6 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
       c->part8.p = (char*)c->part8c.p + (u64)ci * region * 8;
       c->part8.bytes = region * 8;
       if ((rc = part_local(c, true))) return rc;
-      if (!c->part_est) return fail(c, P3_ERETRY_INTERNAL, "position chunks need the estimated-capacity partition");
       HIPCHK(c, hipMemcpyAsync((char*)c->rx_ghist_buf.p + ci * desc, c->ghist.p, desc, hipMemcpyDeviceToDevice, c->stream));
       HIPCHK(c, hipMemcpyAsync((char*)c->rx_segoff_buf.p + ci * desc, c->seg_off.p, desc, hipMemcpyDeviceToDevice, c->stream));
       u64 h[32];
@@ -1217,17 +1256,32 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       const u32 groups = 1u << xg, rows = P3_NB >> xg;
       // (kphase 2: the lumps of the tiled key scatter come through segment by segment)
       const u32 segcap2 = segcap_for(c, krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? c->chunks * 64u : 0u);
-      if ((r2 = ensure(c, c->klpart, (u64)P3_NB * P3_NWG * segcap2 * sizeof(REC)))) return r2;
+      const bool var = var_caps_on(c);  // per-cell capacities from a sample, as in count_split
+      const u64 cap_records = (u64)P3_NB * P3_NWG * segcap2 + (var ? (u64)P3_NB * P3_NWG * segcap2 / 4 : 0);
+      if ((r2 = ensure(c, c->klpart, cap_records * sizeof(REC)))) return r2;
       if ((r2 = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return r2;
       if ((r2 = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return r2;
       if ((r2 = ensure(c, c->zero8, 8 * (P3_MAX_RANKS + 1)))) return r2;
       HIPCHK(c, hipMemsetAsync(c->zero8.p, 0, 8 * (P3_MAX_RANKS + 1), c->stream));
-      LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap2);
+      if (var) {
+        if ((r2 = var_caps_prepare(c))) return r2;
+      } else {
+        LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap2);
+      }
       const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
       for (u32 g = 0; g < groups; g++) {
+        if (var) {
+          LAUNCH(c, "k_cell_sample", (k_cell_sample<REC, (NW == 1 ? 1 : 2)>), P3_NWG, P3_PART_THREADS, (const REC*)c->kpart.p,
+                 (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->zero8.p, 1u, (u32)P3_NB, g * rows, rows, xg,
+                 (u32*)c->cellcnt.p);
+          LAUNCH(c, "k_var_caps", k_var_caps, 1, P3_NB, (u32*)c->cellcnt.p, var_seg_scale(), var_boost_mul(c), segcap2,
+                 cap_records, (u32*)c->caps.p, (u32*)c->seg_off2.p, st + 25);
+        }
         LAUNCH_LDS(c, "k_split", (k_split<REC, (NW == 1 ? 1 : 2)>), P3_NWG, P3_PART_THREADS, lds_split, (const REC*)c->kpart.p,
                    (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->zero8.p, 1u, (u32)P3_NB, g * rows, rows, xg,
-                   (REC*)c->klpart.p, (EstSeg{segcap2, (u32*)c->ghist2.p, st + 25}));
+                   (REC*)c->klpart.p,
+                   (EstSeg{var ? P3_VCAP : segcap2, (u32*)c->ghist2.p, st + 25, var ? (const u32*)c->caps.p : nullptr}),
+                   var ? (const u32*)c->seg_off2.p : nullptr);
         LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB, 1024, lds, (const REC*)c->klpart.p,
                    (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
       }
@@ -1699,7 +1753,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
-                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall};
+                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps};
   for (DevBuf* b : bufs) release(*b);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1738,6 +1792,8 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "tsk_log2") {
     if (value < 4 || value > 14) return fail(c, P3_EBADARG, "tsk_log2 must be in [4,14]");
     c->tsk_log2_opt = (int)value;
+  } else if (n == "var_caps") {
+    c->varcap_opt = value ? 1 : 0;
   } else if (n == "est_boost") {
     c->boost_opt = value ? 0 : 1;  // 1 (default) = graded response, 0 = straight to exact
   } else if (n == "lend") {

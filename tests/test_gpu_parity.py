@@ -528,6 +528,71 @@ def test_mild_skew_is_absorbed_by_a_boosted_estimate(oracle):
     c.close()
 
 
+@pytest.mark.parametrize("k", [31, 41])
+def test_heavy_key_gets_its_own_cell_capacity(oracle, k):
+    """A 40-base poly-A stretch in 950 of 150 k reads: one 21-mer with 19,000 instances.  The first-level partition takes
+    it at boost level 2 (its bucket's segments double), but under the second-level partition (32 groups, forced here;
+    automatic for large inputs) all instances land in ONE of 32,768 cells -- 30x the cell's share, which no boost of a
+    uniform capacity covers.  From the first overflow on the cells' capacities come from a sample of the input
+    (k_cell_sample / k_var_caps): the run stays on the estimated path, equals the oracle, and without that
+    (var_caps = 0) ends on exact offsets with the same results."""
+    n = 150000
+    b, o = synth.reads(seed=43, total_reads=n, read_len=150)
+    b = b.copy()
+    rng = np.random.default_rng(5)
+    starts = o[:-1][rng.choice(n, size=950, replace=False)].astype(np.int64) + 50
+    b[(starts[:, None] + np.arange(40)[None, :]).ravel()] = ord("A")
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    res = []
+    for var in (1, 0):
+        c = capi.Context(0)
+        c.set_option("count_split", 6)
+        c.set_option("kmer_split", 4)
+        c.set_option("var_caps", var)
+        run_and_compare(c, oracle, (b, o), k, m, H)
+        assert c.get_info("est_fallbacks") >= 1
+        if var:
+            assert c.get_info("est_level") in (1, 2) and c.get_info("split_xbits") == 5
+        else:
+            assert c.get_info("est_level") == 3
+        c.run_pass(k, m, H)
+        c.run_pass(k, m, H)
+        keys, counts = c.export_counts()
+        res.append((keys, counts, c.export_bloom()))
+        c.close()
+    assert all(np.array_equal(x, y) for x, y in zip(res[0], res[1]))
+    assert int(res[0][1].max()) >= 15000
+
+
+def test_extreme_key_in_position_chunks_uses_exact_first_level(oracle):
+    """5 % of the reads carry a 40-base poly-A stretch: one 21-mer with 150,000 instances, 8x its bucket's share, so the
+    first-level partition overflows at every boost level.  In the position-chunk form (forced: 4 chunks) the chunks'
+    first-level partitions then take exact offsets (histogram + scan) and the second-level ones sampled per-cell
+    capacities -- the pass stays chunked and partitioned instead of dropping to the direct kernels, and equals the
+    oracle."""
+    n, k = 150000, 31
+    b, o = synth.reads(seed=44, total_reads=n, read_len=150)
+    b = b.copy()
+    rng = np.random.default_rng(6)
+    starts = o[:-1][rng.choice(n, size=n // 20, replace=False)].astype(np.int64) + 50
+    b[(starts[:, None] + np.arange(40)[None, :]).ravel()] = ord("A")
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    c.set_option("chunks", 4)
+    run_and_compare(c, oracle, (b, o), k, m, H)
+    assert c.get_info("est_level") == 3 and c.get_info("chunks") == 4
+    assert c.get_info("count_mode") == 2 and c.get_info("gate_mode") == 2
+    n_fb = c.get_info("est_fallbacks")
+    keys, counts = c.export_counts()
+    words = c.export_bloom()
+    c.run_pass(k, m, H)
+    assert c.get_info("chunks") == 4 and c.get_info("count_mode") == 2 and c.get_info("est_fallbacks") == n_fb
+    k2, c2 = c.export_counts()
+    assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+    assert int(counts.max()) >= 100000
+    c.close()
+
+
 def test_speculative_pass_survives_stale_hints(oracle):
     """p3_run_pass re-uses what the previous pass learnt (table splits, passing-window count, non-solid count) and
     checks only at its single synchronisation point whether that still held.  One context is driven through changes
