@@ -97,8 +97,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "var_caps"    1 (default) = from the first overflow on, the second-level partitions (k_split) size every cell from a
  *                 sample of their input, so that a cell holding a heavy key (poly-A, satellites) gets the room it
  *                 needs; 0 = uniform capacities only (tests).
- *   "lend"        position chunks: 1 = the Bloom stage's scratch buffers are carved from the count stage's partition
- *                 buffer even when device memory is plentiful (tests; default 0 = only when it is short).
+ *   "lend"        position chunks: 1 (default) = the Bloom stage's scratch buffers are carved from the count stage's
+ *                 partition buffer (fresh device memory costs ~30 ms per GiB on the first pass); 0 = only when
+ *                 device memory is short.
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 2x -- fewer bytes to

@@ -101,6 +101,7 @@ struct p3_ctx {
   bool chunk_acc = false;    // do_bloom_t: later chunk (keep the Bloom vector, OR into it), no seeds yet
   int chunk_opt = 0;         // 0 = auto, 1 = never, 2/4/8 = force that many chunks (tests)
   DevBuf part8c, sroff_d;
+  std::vector<DevBuf> outgrown;  // buffers replaced by larger ones, not yet freed (see ensure)
   DevBuf cellcnt, caps;  // k_split with per-cell capacities (after an overflow): sampled counts, capacities
   int varcap_opt = 1;    // tests: 0 = never use per-cell capacities
   // chunked Bloom stage under memory pressure: the count stage's partition buffer is lent to the k-mer stage's
@@ -118,7 +119,7 @@ struct p3_ctx {
   bool kcollect_pass = true;  // this pass: cleared by the first chunk when the collection would not fit in memory
   bool kcollect_ok = true;   // cleared when the collected list's partition overflowed its estimate
   int boost_opt = 0;         // tests: 1 = no boost levels (an overflowing estimate goes straight to exact offsets)
-  int lend_opt = 0;          // tests: 1 = lend the count partitions to the k-mer stage whatever the free memory
+  int lend_opt = 1;          // 1 = always lend the count partitions to the k-mer stage; 0 = only when memory is short
   int kgroup_opt = 0;        // tests: at most this many chunks per collected group (0 = as many as fit in memory)
   int kcollect_opt = 1;      // 0 = probe every chunk's k-mers directly (tests)
   DevBuf dall;
@@ -193,6 +194,11 @@ int fail(p3_ctx* c, int code, const char* fmt, ...) {
 
 void release(DevBuf& b);
 
+void free_outgrown(p3_ctx* c) {
+  for (DevBuf& g : c->outgrown) release(g);
+  c->outgrown.clear();
+}
+
 bool lendable(const p3_ctx* c, const DevBuf& b) {
   return &b == &c->kpart || &b == &c->klpart || &b == &c->dkeys || &b == &c->dall || &b == &c->ppart;
 }
@@ -210,10 +216,23 @@ int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
       return P3_OK;
     }
   }
+  // A buffer that has to grow is not freed on the spot: hipFree synchronises the device, and a hipMalloc that follows
+  // the hipFree of gigabytes was measured at 0.1-3 s (the first pass over 50 M reads spent 2.4 of its 2.7 s there).
+  // Outgrown buffers of 64 MiB and more wait in c->outgrown until new reads arrive, the context goes, or memory runs out.
+  if (b.p && !b.borrowed && b.bytes >= (64u << 20)) {
+    c->outgrown.push_back(b);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
   if (b.p) release(b);
   static const bool trace = getenv("P3_TRACE_ALLOC") != nullptr;  // diagnostic: log every device (re)allocation >= 256 MiB
   const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&b.p, bytes ? bytes : 16);
+  if (e == hipErrorOutOfMemory && !c->outgrown.empty()) {
+    (void)hipGetLastError();
+    free_outgrown(c);
+    e = hipMalloc(&b.p, bytes ? bytes : 16);
+  }
   if (trace && bytes >= (256u << 20))
     fprintf(stderr, "[p3] hipMalloc %.2f GiB: %.1f ms\n", (double)bytes / (1u << 30),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -361,6 +380,7 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->graphed = false;
   c->reads_epoch++;
   c->hint_valid = false;
+  free_outgrown(c);
   c->est_ok = true;
   c->chunk_ok = true;
   c->est_boost = 0;
@@ -1616,11 +1636,13 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   if ((rc = ensure(c, c->P, nwa * 4))) return rc;
   // The count stage is done with its partitions (tens of GB).  Freeing them is not an option: a hipMalloc that
-  // follows the hipFree of a buffer this size was measured at 1-3 s (32M reads; 0.3 ms otherwise), ten times the
-  // kernels of the pass.  When the k-mer buffers (about as large again) might not fit beside them, the partition
-  // buffer is LENT to them for the duration of this stage instead.
+  // follows the hipFree of a buffer this size was measured at 1-3 s (32M reads), ten times the kernels of the pass --
+  // and fresh device memory costs about 30 ms per GiB anyway (the first pass over 32 M reads spent 2.5 of its 2.8 s
+  // in hipMalloc).  So the partition buffer is LENT to the k-mer stage's scratch buffers for the duration of this
+  // stage: they are carved from it (LendScope), and only what does not fit is allocated.  ("lend" = 0: only when
+  // the free memory is short, the earlier behaviour, kept for tests.)
   size_t mem_free0 = 0, mem_total0 = 0;
-  const bool tight = hipMemGetInfo(&mem_free0, &mem_total0) != hipSuccess || mem_free0 < 2 * c->part8c.bytes || c->lend_opt;
+  const bool tight = c->lend_opt != 0 || hipMemGetInfo(&mem_free0, &mem_total0) != hipSuccess || mem_free0 < 2 * c->part8c.bytes;
   DevBuf nothing;
   LendScope lend(c, tight ? c->part8c : nothing);
   if ((rc = ensure(c, c->bloom, bwords * 8))) return rc;
@@ -1755,6 +1777,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
                     &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps};
   for (DevBuf* b : bufs) release(*b);
+  free_outgrown(c);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
