@@ -1,7 +1,25 @@
 // p3_lib.hip -- context management and the C ABI of include/platanus3_amd.h (gfx950 only).
 //
-// Host-side orchestration of the HIP kernels in p3_kernels.h.  No CPU compute fallback exists: every
+// Host-side orchestration of the HIP kernels in p3_kernels*.h.  No CPU compute fallback exists: every
 // stage runs on the device or the call fails with P3_EHIP.
+//
+// Map of this file, top to bottom:
+//   p3_ctx, DevBuf                   state of one device context; all device buffers; options; hints
+//   fail / ensure / release / LendScope / free_outgrown     errors and device memory (lending, parked buffers)
+//   drain_stats, LAUNCH macros       per-kernel HIP-event statistics
+//   set_reads_common, do_pack        T1/E1-E3: reads in HBM -> 2-bit streams + read-end mask
+//   do_count_direct                  C1, global hash table (fallback)
+//   segcap_for / est_overflowed      estimated segment capacities and the graded response to skew
+//   part_local, repartition_rx, count_owned, count_split, var_caps_*   C1 partitioned: first level, owner-side
+//                                    re-partition, LDS-table count, second-level groups, per-cell capacities
+//   solid_build, solid_bits          G1 gate inputs: solid regions (table form) / non-solid positions (return path)
+//   agg_local                        multi-rank: sender-side pre-aggregation
+//   do_count_part, ChunkView, chunks_for, do_count_chunked, do_count   the count stage's drivers
+//   do_bloom_t, bloom_chunked        G1/G2/B1: gate, k-mer partition + dedup (+ collection over chunks), probes,
+//                                    LDS slices, seeds
+//   build_graph_t                    G3-G5: de Bruijn stage
+//   extern "C"                       the ABI: context, options/info, loads, p3_mr_* protocol steps, graph exports,
+//                                    p3_count_short / p3_make_bloom / p3_run_pass (speculative single-sync pass)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
