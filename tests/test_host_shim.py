@@ -14,15 +14,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "platanus3_amd", "host")
 
 
+_exe = []
+
+
 def _compile(tmp_path, syntax_only=False):
+    if _exe and not syntax_only:   # (one build per session: ~3.5 s each)
+        return _exe[0]
     _build.build_lib()
-    exe = os.path.join(str(tmp_path), "assemble_demo")
+    import tempfile
+    exe = os.path.join(str(tmp_path) if syntax_only else tempfile.mkdtemp(prefix="p3shim_"), "assemble_demo")
     cmd = ["g++", "-std=c++17", "-O2", "-I" + _build.INCLUDE, "-I" + HOST, os.path.join(HOST, "assemble_demo.cpp")]
     if syntax_only:
         cmd.insert(1, "-fsyntax-only")
     else:
         cmd += ["-o", exe, "-L" + _build.CSRC, "-lplatanus3_amd", "-Wl,-rpath," + _build.CSRC, "-pthread"]
     subprocess.check_call(cmd)
+    if not syntax_only:
+        _exe.append(exe)
     return exe
 
 
