@@ -20,10 +20,18 @@
 #define P3_EMPTY_KEY (~0ULL)
 #define P3_PAD_WORDS 4  // stream words past the last base, so every lane may read w..w+3
 
+// the 32 2-bit groups of x in reverse order (group i <-> group 31 - i), bits inside a group kept
+__device__ __forceinline__ u64 sk_pairs_reversed(u64 x) {
+  u64 y = __brevll(x);
+  return ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+}
+
 // ---- k_pack: ASCII -> 2-bit forward stream (MSB-first) + complement stream (LSB-first) ---------------
 __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ bases, u64 n_bases, u64 n_words_alloc,
-                                              u64* __restrict__ fw, u64* __restrict__ rcw, int aligned16) {
+                                              u64* __restrict__ fw, u64* __restrict__ rcw, int aligned16,
+                                              u32* __restrict__ unknown_flag) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
+  bool unknown = false;  // a base other than A/C/G/T (the run-record kernels need to know: p3_kernels_sk.h)
   for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words_alloc; w += stride) {
     const u64 b0 = w * 32;
     u64 f = 0, r = 0;
@@ -43,6 +51,8 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ bases,
           r |= (u64)rc << (2 * j);
         }
       }
+      // known base <=> forward code + rc code == 3 in every 2-bit group (unknown: 0 + 0); r is bit-reversed pairs
+      unknown |= (f ^ sk_pairs_reversed(r)) != ~0ULL;
     } else if (b0 < n_bases) {
       const u32 n = (u32)((n_bases - b0) < 32 ? (n_bases - b0) : 32);
       for (u32 j = 0; j < n; j++) {
@@ -50,11 +60,13 @@ __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ bases,
         base_codes(bases[b0 + j], fc, rc);
         f |= (u64)fc << (62 - 2 * j);
         r |= (u64)rc << (2 * j);
+        unknown |= (fc + rc) != 3u;
       }
     }
     fw[w] = f;
     rcw[w] = r;
   }
+  if (unknown) *unknown_flag = 1u;
 }
 
 // ---- k_endmask: bit p set <=> base p is the last base of an admitted read, or belongs to a dropped

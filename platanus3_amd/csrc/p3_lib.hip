@@ -37,6 +37,7 @@
 #include "p3_kernels_part.h"
 #include "p3_kernels_bloom.h"
 #include "p3_kernels_retgate.h"
+#include "p3_kernels_sk.h"
 #include "p3_kernels_dbg.h"
 
 namespace {
@@ -99,6 +100,8 @@ struct p3_ctx {
   bool est_ok = true;       // cleared when an estimated segment overflowed at the last boost level (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0, ksbits_k = 0;
   u64 ksbits_epoch = ~0ull;
+  u32 sbits_sk = 0;          // sub-bucket split the run-record count needed for the reads of sbits_epoch
+  u64 sbits_epoch = ~0ull;
   DevBuf kpart, dkeys, ppart, scan_tmp;
   // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
   u32 rank = 0, n_ranks = 1;
@@ -175,6 +178,19 @@ struct p3_ctx {
   u64 hint_m = 0, reads_epoch = 0, hint_epoch = 0;
   int bloom_slices_opt = 1;  // 1 = sliced LDS OR after dedup (when it fits), 0 = global atomicOr per probe
   u64 n_distinct_k = 0;
+
+  // run-length ("super-k-mer") records, p3_kernels_sk.h: the partition stages move one 16-byte record per RUN of
+  // windows.  sk_opt: 0 = automatic, 1 = never, 2 = wherever the form applies (tests).  sk_ok is cleared, until new
+  // reads arrive, when the form turned out not to fit the input (unknown bases, a capacity that overflowed twice, a
+  // count that outgrew the 22-bit slot field): the per-window kernels then take over.
+  int sk_opt = 0;
+  bool sk_ok = true;
+  u32 sk_boost = 0;          // 0 = expected run density, 1 = one record per window (worst case)
+  bool part_sk = false;      // the current count partition holds run records (16 B)
+  bool kpart_sk = false;     // ... and so does the current k-mer partition
+  u32 sk_segcap = 0, sk_ksegcap = 0;
+  int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
+  DevBuf unk_flag;           // set by k_pack when a base is not A/C/G/T
 
   // bloom
   DevBuf bloom, seeds, seed_valid;
@@ -400,6 +416,8 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->hint_valid = false;
   free_outgrown(c);
   c->est_ok = true;
+  c->sk_ok = true;
+  c->sk_boost = 0;
   c->chunk_ok = true;
   c->est_boost = 0;
   c->kcollect_ok = true;
@@ -416,9 +434,12 @@ int do_pack(p3_ctx* c) {
   if ((rc = ensure(c, c->fw, nwa * 8))) return rc;
   if ((rc = ensure(c, c->rcw, nwa * 8))) return rc;
   if ((rc = ensure(c, c->endm, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->unk_flag, 16))) return rc;
   HIPCHK(c, hipMemsetAsync(c->endm.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->unk_flag.p, 0, 16, c->stream));
   const int aligned = (((uintptr_t)c->d_bases) & 15) == 0;
-  LAUNCH(c, "k_pack", k_pack, grid_for(nwa), 256, c->d_bases, c->n_bases, nwa, (u64*)c->fw.p, (u64*)c->rcw.p, aligned);
+  LAUNCH(c, "k_pack", k_pack, grid_for(nwa), 256, c->d_bases, c->n_bases, nwa, (u64*)c->fw.p, (u64*)c->rcw.p, aligned,
+         (u32*)c->unk_flag.p);
   LAUNCH(c, "k_endmask", k_endmask, grid_for(c->n_reads + 1), 256, c->d_offsets, c->n_reads, c->min_len,
          (u32*)c->endm.p, c->n_bases, nwa * 32);
   c->packed = true;
@@ -495,6 +516,40 @@ void est_overflowed(p3_ctx* c) {
 
 bool est_mode(const p3_ctx* c) { return c->n_ranks == 1 && !c->protocol && c->est_ok && c->sizing_opt != 1; }
 
+double active_wgs(u64 n_words);
+
+// ---- run-length records (p3_kernels_sk.h): when the form is used ----------------------------------------------------
+// One rank, one position range, estimated capacities, none of the test options that select a particular per-window
+// path, and reads without unknown bases (known after the first k_pack over them: sk_ok).
+bool sk_on(const p3_ctx* c) {
+  if (c->sk_opt == 1 || !c->sk_ok) return false;
+  if (!est_mode(c) || c->chunks != 1 || c->n_words * 32 > (1ull << 30)) return false;
+  if (c->sk_opt == 2) return true;
+  return c->count_mode_opt == 0 && c->gate_mode_opt == 0 && c->bloom_mode_opt == 0 && c->split_opt == 0 &&
+         c->ksplit_opt == 0 && c->dbg_opt == 0 && c->ts_log2_opt == P3_TS_LOG2_MAX && c->tsk_log2_opt == 14 &&
+         c->chunk_opt == 0 && c->est_boost == 0;
+}
+// records per (bucket, workgroup) segment for `windows` windows cut into runs: a run ends where the minimizer changes
+// (every (w + 1) / 2 windows for random sequence, w = m-mers per k-mer), at the word boundary (1 / 32) and at a read
+// end; buckets of minimizers are less even than buckets of hashed keys (+25 %).  sk_boost = 1: one record per window.
+u32 sk_segcap_for(const p3_ctx* c, double windows, u32 w_mmers) {
+  const double per_window = c->sk_boost ? 1.0 : (2.0 / (w_mmers + 1) + 1.0 / 32 + 1.0 / 100) * 1.25;
+  const double mean = windows * per_window / ((double)P3_NB * active_wgs(c->n_words));
+  return ((u32)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15u) & ~15u;
+}
+// the run-record form did not fit (a full segment, a count beyond the slot field, unknown bases): next level or off
+void sk_failed(p3_ctx* c, bool retry_larger) {
+  if (retry_larger && c->sk_boost == 0) c->sk_boost = 1;
+  else c->sk_ok = false;
+}
+u32 sk_initial_sbits(u64 windows, u32 ts_log2) {
+  // <= 6 instances per usable slot (7/8 of the table): ~30x coverage with sequencing errors gives one distinct key
+  // per 7 instances; a wrong guess costs one repeated count launch
+  u32 sbits = 0;
+  while (sbits < 6 && windows / ((u64)P3_NB << sbits) > 6ull * ((7ull << ts_log2) >> 3)) sbits++;
+  return sbits;
+}
+
 // records one workgroup of the hist/scatter kernels can emit at most (its share of the stream words x 32)
 u64 wg_window_bound(const p3_ctx* c) {
   u64 per = (c->n_words + P3_NWG - 1) / P3_NWG;
@@ -551,7 +606,17 @@ int part_local(p3_ctx* c, bool with_pos) {
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
   const size_t lds8 = (size_t)P3_STAGE_WORDS * 4;
-  if (est) {
+  c->part_sk = false;
+  if (est && sk_on(c)) {
+    // run-length records: one 16-byte record per run of windows, written straight into fixed-stride segments
+    const double windows = c->host_windows ? (double)c->host_windows : (double)c->n_words * 32;
+    const u32 cap = sk_segcap_for(c, windows, SK_W21);
+    if ((rc = ensure(c, c->part8, (u64)P3_NB * P3_NWG * cap * 16))) return rc;
+    LAUNCH(c, "k_sk_scatter21", k_sk_scatter21, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (uint4*)c->part8.p, (SkSeg{cap, (u32*)c->ghist.p, st + 26}), st + 5);
+    c->part_sk = true;
+    c->sk_segcap = cap;
+  } else if (est) {
     // no histogram pass and no scan: fixed-stride segments; the scatter reports what it wrote
     if ((rc = fixed_segoff(c, segcap))) return rc;
     LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds8, (const u64*)c->fw.p,
@@ -672,8 +737,18 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if ((rc = set_k2ext(c, maxd, c->n_ranks > 1 ? c->rx_roff.p : nullptr, c->n_ranks))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  const u32 ts_log2 = (u32)c->ts_log2_opt;
-  if (c->part_pos) {
+  const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
+  if (c->part_sk) {
+    if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
+    if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
+    const u32 nwaves = 16;
+    const size_t lds = ((size_t)8 << ts_log2) + nwaves * (64 * 16 + SK_QCAP * 12) + P3_NWG * 4 + 64;
+    LAUNCH_LDS(c, "k_sk_count", k_sk_count, nsb, nwaves * 64, lds, (const uint4*)kpart, (const u32*)khist, c->sk_segcap, sbits,
+               ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
+               (u64*)c->sing_cursor.p);
+    HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+  } else if (c->part_pos) {
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;  // (src|slot|pos) per first instance
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
     if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
@@ -708,11 +783,22 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     return P3_OK;
   }
   u64 h[32];
+  u32 unk[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  if (c->part_sk) HIPCHK(c, hipMemcpyAsync(unk, c->unk_flag.p, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->part_sk && (unk[0] || h[26] || h[3] == 2)) {
+    sk_failed(c, !unk[0] && h[26] && h[3] != 2);
+    return fail(c, P3_ERETRY_INTERNAL, "run records do not fit these reads (unknown bases %u, full segment %llu, table flag %llu)",
+                unk[0], (unsigned long long)h[26], (unsigned long long)h[3]);
+  }
   if (h[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     est_overflowed(c);
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded");
+  }
+  if (c->part_sk && h[3] == 0) {
+    c->sbits_sk = sbits;
+    c->sbits_epoch = c->reads_epoch;
   }
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
@@ -867,7 +953,13 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
   if (est) {
     u64 per = (n_est + n_est / 16 + P3_NWG - 1) / P3_NWG;
     per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
-    const u32 segcap = segcap_for(c, (double)per / (ns ? ns : 1));
+    u32 segcap = segcap_for(c, (double)per / (ns ? ns : 1));
+    if (c->part_sk) {
+      // the run-record count emits the windows of a run (<= 12 neighbouring positions, the trace of one sequencing
+      // error) next to each other in the list, so a workgroup's share of a slice comes in lumps: compound-Poisson margin
+      const double mean = (double)per / (ns ? ns : 1);
+      segcap = ((u32)(mean + 6.0 * std::sqrt(12.0 * mean) + 32.0) + 15u) & ~15u;
+    }
     if ((rc = ensure(c, c->ns_part, (u64)P3_NB * P3_NWG * segcap * 4))) return rc;
     if ((rc = fixed_segoff(c, segcap))) return rc;
     LAUNCH_LDS(c, "k_u32_scatter", k_u32_scatter, P3_NWG, P3_PART_THREADS, lds_sc, d_positions, d_n_pos, slice_log2,
@@ -998,13 +1090,20 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
   // on the second-level partition pays (3 M reads: 9.9 vs 11.1 ms; 6.25 M: 22.0 vs 32.8 ms)
   u32 first = initial_sbits(c->n_words * 32);
   c->split_xbits = 0;
-  if (with_pos && c->part_est && c->split_opt != 1) {
+  if (c->part_sk) {
+    first = sk_initial_sbits(c->host_windows ? c->host_windows : c->n_words * 32, (u32)c->sk_ts_log2_opt);
+    if (c->sbits_epoch == c->reads_epoch && c->sbits_sk > first) first = c->sbits_sk;  // what the last pass needed
+  } else if (with_pos && c->part_est && c->split_opt != 1) {
     if (c->split_opt >= 2) c->split_xbits = (u32)c->split_opt - 1;
     else if (first >= 3) c->split_xbits = first;
     if (c->split_xbits) first = 0;
   }
   for (u32 sbits = first;; sbits++) {
-    if (sbits > 5) {
+    if (sbits > (c->part_sk ? 6u : 5u)) {
+      if (c->part_sk) {  // (more than 64 tables per bucket: the per-window form has a second-level partition for that)
+        sk_failed(c, false);
+        return fail(c, P3_ERETRY_INTERNAL, "run records: a table overflowed at every sub-bucket split");
+      }
       *overflowed = true;
       return P3_OK;
     }
@@ -1245,7 +1344,17 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (c->kphase == 2) mean_k = (double)c->dall_n * 1.02 / ((double)P3_NB * P3_NWG);
     // (kphase 2: the list holds same-bucket runs, one per chunk and dedup cell, and the scatter deals them out in
     // 16-key tiles, so a (bucket, workgroup) segment receives its share give or take a tile per run: extra margin)
-    const u32 segcap_k = est ? segcap_for(c, mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
+    u32 segcap_k = est ? segcap_for(c, mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
+    // run-length records for the passing k-mers (k <= 32; p3_kernels_sk.h): the count stage used them, so the reads
+    // are known to suit them
+    const bool sk_k = NW == 1 && est && c->kphase == 0 && c->part_sk && sk_on(c) && c->s_ready;
+    c->kpart_sk = false;
+    if (sk_k) {
+      const double kwin = c->pass_hint && c->pass_hint_k == k ? (double)c->pass_hint * 1.02
+                          : c->host_windows ? (double)c->host_windows : (double)c->n_words * 32;
+      segcap_k = sk_segcap_for(c, kwin, k - SK_M + 1) * 2;  // (16-byte records in a buffer of 8-byte REC)
+      c->sk_ksegcap = segcap_k / 2;
+    }
     if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
@@ -1258,6 +1367,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
       LAUNCH_LDS(c, "k_keys_scatter", (k_keys_scatter<NW>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dall.p, c->dall_n,
                  (REC*)c->kpart.p, (EstSeg{segcap_k, (u32*)c->ghist.p, st + 27}));
+    } else if (sk_k) {
+      HIPCHK(c, hipMemsetAsync(st + 28, 0, 8, c->stream));
+      LAUNCH(c, "k_sk_kscatter", k_sk_kscatter, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+             (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k, (uint4*)c->kpart.p,
+             (SkSeg{c->sk_ksegcap, (u32*)c->ghist.p, st + 28}), st + 8);
+      c->kpart_sk = true;
     } else if (est) {
       // estimated segment capacities: the scatter evaluates the gate itself (P, statistics) -- no histogram pass
       if ((rc = fixed_segoff(c, segcap_k))) return rc;
@@ -1273,6 +1388,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                  (const u32*)c->seg_off.p, (REC*)c->kpart.p, (EstSeg{0, nullptr, nullptr}), st + 8);
     }
     u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 2 : 0);  // 16 Ki x 8 B or 4 Ki x 20 B slots
+    if (c->kpart_sk) ts_log2 = (u32)c->sk_ts_log2_opt;
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
     const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
                        16 * 192 * sizeof(REC);
@@ -1284,6 +1400,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                                            : mean_k * (double)P3_NB * active_wgs(c->n_words);  // estimate of the passing k-mers
     auto dedup_once = [&](u32 sb, u32 xg) -> int {
       HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
+      if (c->kpart_sk) {
+        const u32 nwaves = 16;
+        const size_t lds_sk = ((size_t)8 << ts_log2) + nwaves * (64 * 16 + SK_QCAP * 8) + P3_NWG * 4 + 64;
+        LAUNCH_LDS(c, "k_sk_dedup", k_sk_dedup, P3_NB << sb, nwaves * 64, lds_sk, (const uint4*)c->kpart.p,
+                   (const u32*)c->ghist.p, c->sk_ksegcap, sb, ts_log2, k, (u64*)c->dkeys.p, dst);
+        return P3_OK;
+      }
       if (!xg) {
         LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sb, 1024, lds, (const REC*)c->kpart.p,
                    (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst,
@@ -1331,6 +1454,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       if ((rc = dedup_once(sbits, kxg))) return rc;
     } else {
       while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
+      if (c->kpart_sk)  // 8 Ki-slot sets: <= 8 instances per slot to start with
+        for (sbits = 0; sbits < 6 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (8ull << ts_log2); sbits++) {}
       // the split that worked for the previous pass over the same reads and k is the best first guess
       if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k) {
         if (c->kxg) {
@@ -1354,11 +1479,16 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         sbits = 0;
       }
       for (;;) {
-        if (!kxg && sbits >= 3 && est && c->split_opt != 1) {  // an 8-way split or finer: partition the k-mers once more
+        if (c->kpart_sk && sbits > 6) {
+          sk_failed(c, false);
+          c->counted = false;
+          return fail(c, P3_ERETRY_INTERNAL, "run records: a k-mer set overflowed at every sub-bucket split");
+        }
+        if (!c->kpart_sk && !kxg && sbits >= 3 && est && c->split_opt != 1) {  // an 8-way split or finer: partition the k-mers once more
           kxg = sbits;
           sbits = 0;
         }
-        if ((!kxg && sbits > 5) || kxg > 10) {
+        if (!c->kpart_sk && ((!kxg && sbits > 5) || kxg > 10)) {
           use_dedup = false;  // every split overflowed: fall back to the direct form below
           break;
         }
@@ -1479,10 +1609,19 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
            (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 hall[32];
+  u32 unk[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hall, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
   if (c->spec && c->part_pos)
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+  if (c->part_sk && c->unk_flag.p) HIPCHK(c, hipMemcpyAsync(unk, c->unk_flag.p, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((c->part_sk && c->spec && (unk[0] || hall[26] || hall[3] == 2)) || (c->kpart_sk && hall[28])) {
+    // run records did not fit (checked here for a single-synchronisation pass; the k-mer records in any case)
+    sk_failed(c, !unk[0] && hall[3] != 2);
+    c->counted = false;
+    return fail(c, P3_ERETRY_INTERNAL, "run records do not fit these reads (unknown bases %u, full segment %llu / %llu, table flag %llu)",
+                unk[0], (unsigned long long)hall[26], (unsigned long long)hall[28], (unsigned long long)hall[3]);
+  }
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
   if (c->kphase == 2 && hall[27]) {
     c->kcollect_ok = false;  // (the per-chunk form still works: no need to give up the estimates altogether)
@@ -1860,6 +1999,12 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "mr_aggregate") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
     c->agg_opt = (int)value;
+  } else if (n == "run_records") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "run_records must be 0 (auto), 1 (never) or 2 (wherever they apply)");
+    c->sk_opt = (int)value;
+  } else if (n == "sk_ts_log2") {
+    if (value < 6 || value > 13) return fail(c, P3_EBADARG, "sk_ts_log2 must be in [6,13]");
+    c->sk_ts_log2_opt = (int)value;
   } else if (n == "ts_log2") {
     if (value < 4 || value > P3_TS_LOG2_MAX) return fail(c, P3_EBADARG, "ts_log2 must be in [4,%d]", P3_TS_LOG2_MAX);
     c->ts_log2_opt = (int)value;
@@ -1880,6 +2025,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "ksplit_xbits") *value = c->kxg;
   else if (n == "distinct_kmers") *value = (int64_t)c->n_distinct_k;
   else if (n == "sbits") *value = c->sbits;
+  else if (n == "run_records") *value = (c->part_sk ? 1 : 0) | (c->kpart_sk ? 2 : 0);
   else if (n == "rs_log2") *value = c->rs_log2;
   else if (n == "split_xbits") *value = c->split_xbits;
   else if (n == "chunks") *value = c->chunks;
