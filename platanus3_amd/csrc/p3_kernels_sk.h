@@ -11,12 +11,14 @@
 // (w = k - SK_M + 1 m-mers per k-mer).
 //
 //   k_sk_scatter21   canonical 21-mers (C1, src/Load.cpp:113-125): runs of <= 12 windows -> Rec16 {32 bases | start
-//                    position, length, sub-bucket bits}, written straight into the (bucket, workgroup) segment: one LDS
-//                    cursor ticket per RUN, no staging rows, no barriers
-//   k_sk_count       one workgroup per (bucket, sub-bucket): accepted records are compacted into a per-wave LDS ring,
-//                    lanes pop a record whenever theirs is exhausted (so the table loop runs with full lanes whatever
-//                    the run lengths), 8-byte LDS slots (42-bit key | 22-bit count), misses through a per-wave queue;
-//                    first-instance positions -> non-solid window list as in k_part_count (return-path gate)
+//                    position, length, sub-bucket bits}, written straight into the (fine bucket, workgroup) segment: one
+//                    LDS cursor ticket per RUN, no staging rows, no barriers.  There are 1024 << fbits FINE buckets (the
+//                    cursors are all the LDS the kernel needs), so that a consumer workgroup reads what it counts and
+//                    nothing else
+//   k_sk_count       one workgroup per fine bucket: 64 records per wave and round -> one task per window -> steps of 64
+//                    tasks, four interleaved (full lanes whatever the run lengths), 8-byte LDS slots (42-bit key | 22-bit
+//                    count), misses through a per-wave queue; first-instance positions -> non-solid window list as in
+//                    k_part_count (return-path gate)
 //   k_sk_kscatter    passing canonical k-mers (src/MakeBloomFilter.cpp:62-77): runs of passing windows -> Rec16
 //                    {58 bases | length, sub-bucket bits}; writes the pass bitmap P and the statistics
 //   k_sk_dedup       LDS key set per (bucket, sub-bucket) -> distinct canonical k-mers (BF::add is idempotent)
@@ -78,11 +80,13 @@ struct SkSeg {
 // stats[0] += valid windows.
 __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                   const u32* __restrict__ endm, u64 n_words,
-                                                                  uint4* __restrict__ part, SkSeg seg,
+                                                                  uint4* __restrict__ part, SkSeg seg, u32 fbits,
                                                                   u64* __restrict__ stats) {
-  __shared__ u32 cursor[P3_NB];
-  __shared__ u32 s_valid;
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) cursor[i] = 0;
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 NF = P3_NB << fbits, cshift = 6u - fbits;  // fine bucket = top 10 + fbits bits of the 16-bit code
+  u32* cursor = lds;
+  u32& s_valid = lds[NF];
+  for (u32 i = threadIdx.x; i < NF; i += blockDim.x) cursor[i] = 0;
   if (threadIdx.x == 0) s_valid = 0;
   __syncthreads();
   u64 begin, end;
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __r
         if (e <= 64) lo = L.W0 >> (64 - e);
         else lo = (L.W0 << (e - 64)) | (L.W1 >> (128 - e));
         const u32 code = sk_code(sig[j]);
-        const u32 b = code >> 6;
+        const u32 b = code >> cshift;
         const u32 ticket = atomicAdd(&cursor[b], 1u);
         if (ticket < seg.segcap) {
           const u32 hi0 = pos0 + (u32)j + 1u - len;
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __r
   for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off, 64);
   if ((threadIdx.x & 63) == 0 && n_valid) atomicAdd(&s_valid, n_valid);
   __syncthreads();
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+  for (u32 i = threadIdx.x; i < NF; i += blockDim.x) {
     const u32 n = cursor[i];
     seg.ghist_out[i * P3_NWG + blockIdx.x] = n < seg.segcap ? n : seg.segcap;
   }
@@ -152,49 +156,72 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __r
 }
 
 // ---- per-wave record feed -----------------------------------------------------------------------------------------------
-// Bucket pb = P3_NWG segments of `segcap` record slots each, cnt[] (LDS) records in use.  Wave v of the workgroup
-// takes segments v, v + nwaves, ...; 64 records per load, the next load in flight while the previous one is used.
-// (Plain locals + a lambda: as a struct passed by reference the state went to scratch memory.)
+// A consumer workgroup reads ONE fine bucket = P3_NWG segments of `segcap` record slots, cnt[] (LDS) records in use.
+// Wave v takes segments v, v + nwaves, ... as one flattened stream, 64 records per ROUND whatever the segment sizes
+// (every lane computes its own source address).  (Plain locals + lambdas: as a struct the state went to scratch.)
 #define SK_FEED_DECL(seg0_expr)                                                                      \
   const uint4* const f_seg0 = (seg0_expr);                                                           \
   u32 f_si = wave, f_bo = 0;                                                                         \
-  bool f_done = false, f_nval = false;                                                               \
-  uint4 f_nrec = make_uint4(0u, 0u, 0u, 0u);                                                         \
-  auto feed_issue = [&]() {                                                                          \
-    while (f_si < P3_NWG && f_bo >= cnt[f_si]) { /* next non-empty stretch (wave-uniform) */         \
-      f_si += nwaves;                                                                                \
-      f_bo = 0;                                                                                      \
+  auto feed_round = [&](bool& v, u32& nrec) -> const uint4* { /* next <= 64 records */               \
+    u32 acc = 0;                                                                                     \
+    const uint4* p = f_seg0;                                                                         \
+    v = false;                                                                                       \
+    while (acc < 64 && f_si < P3_NWG) {                                                              \
+      const u32 c = cnt[f_si];                                                                       \
+      const u32 room = 64u - acc, left = c - f_bo;                                                   \
+      const u32 take = left < room ? left : room;                                                    \
+      if (lane - acc < take) { /* (unsigned: lane >= acc too) */                                     \
+        p = f_seg0 + ((u64)f_si * segcap + f_bo + (lane - acc));                                     \
+        v = true;                                                                                    \
+      }                                                                                              \
+      acc += take;                                                                                   \
+      f_bo += take;                                                                                  \
+      if (f_bo >= c) {                                                                               \
+        f_si += nwaves;                                                                              \
+        f_bo = 0;                                                                                    \
+      }                                                                                              \
     }                                                                                                \
-    if (f_si >= P3_NWG) {                                                                            \
-      f_done = true;                                                                                 \
-      f_nval = false;                                                                                \
-      return;                                                                                        \
-    }                                                                                                \
-    f_nval = f_bo + lane < cnt[f_si];                                                                \
-    f_nrec = f_seg0[(u64)f_si * segcap + (f_nval ? f_bo + lane : 0u)];                               \
-    f_bo += 64;                                                                                      \
-  };                                                                                                 \
-  feed_issue()
+    nrec = acc;                                                                                      \
+    return p;                                                                                        \
+  }
 
 // ---- k_sk_count -----------------------------------------------------------------------------------------------------------
-// gstats / sb_info / tpairs / singles / sing_cursor: as k_part_count<true> with one source.
-// LDS: table u64[TS] | ring uint4[nwaves][64] | qkey u64[nwaves][128] | qpos u32[nwaves][128] | cnt u32[256] | scalars
+// gstats / sb_info / tpairs / singles / sing_cursor: as k_part_count<true> with one source; out_cap = entries that
+// out_keys / out_counts hold.  One workgroup per (fine bucket, extra sub-bucket): fbits of the code's six sub-bucket bits
+// were spent by the scatter on separate segments; xbits more (normally 0) are filtered here, every fine bucket then
+// being read 2^xbits times.
+//
+// The kernel is bound by instruction issue and LDS LATENCY at 16 waves per CU (the table leaves room for one
+// workgroup), not by LDS or HBM bandwidth, so each wave works in ROUNDS with regular, branch-light control flow:
+//   load     64 records (the next round's load is in flight meanwhile)
+//   decode   reverse complement etc. in registers, once per record, all lanes busy; -> the wave's round buffer
+//   expand   one 16-bit task (record << 4 | window) per WINDOW: prefix sums of the run lengths from four ballots,
+//            twelve predicated 2-byte stores
+//   process  64 tasks per step whatever the run lengths, FOUR steps interleaved (their LDS round trips overlap): window
+//            -> canonical 21-mer -> home slot of the 8-byte LDS table (42-bit key | 22-bit count); a hit is one LDS add,
+//            misses go through the per-wave queue and are inserted 64 at a time (double hashing)
+// LDS: table u64[TS] | per wave: rbA uint4[64] (bases, reverse complement), rbB uint2[64] (last position, windows),
+//      tasks u16[768 + 64], qkey u64[128], qpos u32[128] | cnt u32[256] | scalars
 #define SK_QCAP 128u
+#define SK_TASKS 768u  // tasks of one round: 64 records x <= 12 windows
+#define SK_WAVE_LDS (64u * 24u + (SK_TASKS + 64u) * 2u + SK_QCAP * 12u)
 __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
-                                                   u32 sbits, u32 ts_log2, u64* __restrict__ out_keys,
+                                                   u32 fbits, u32 xbits, u32 ts_log2, u64* __restrict__ out_keys,
                                                    u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                    u64* __restrict__ gstats, u64* __restrict__ tpairs,
-                                                   u32* __restrict__ singles, u64* __restrict__ sing_cursor) {
+                                                   u32* __restrict__ singles, u64* __restrict__ sing_cursor, u64 out_cap,
+                                                   u32 dbg) {
   extern __shared__ __align__(16) u32 lds[];
   const u32 TS = 1u << ts_log2;
   const u32 nwaves = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   u64* tab = reinterpret_cast<u64*>(lds);
-  uint4* ring = reinterpret_cast<uint4*>(tab + TS) + wave * 64;
-  u64* qkey = reinterpret_cast<u64*>(reinterpret_cast<uint4*>(tab + TS) + nwaves * 64) + wave * SK_QCAP;
-  u32* qpos = reinterpret_cast<u32*>(reinterpret_cast<u64*>(reinterpret_cast<uint4*>(tab + TS) + nwaves * 64) + nwaves * SK_QCAP) +
-              wave * SK_QCAP;
-  u32* cnt = reinterpret_cast<u32*>(reinterpret_cast<u64*>(reinterpret_cast<uint4*>(tab + TS) + nwaves * 64) + nwaves * SK_QCAP) +
-             nwaves * SK_QCAP;
+  char* wbase = reinterpret_cast<char*>(tab + TS) + (size_t)wave * SK_WAVE_LDS;
+  uint4* rbA = reinterpret_cast<uint4*>(wbase);
+  uint2* rbB = reinterpret_cast<uint2*>(wbase + 64u * 16u);
+  unsigned short* tasks = reinterpret_cast<unsigned short*>(wbase + 64u * 24u);  // [SK_TASKS] + 64 trash entries
+  u64* qkey = reinterpret_cast<u64*>(wbase + 64u * 24u + (SK_TASKS + 64u) * 2u);
+  u32* qpos = reinterpret_cast<u32*>(wbase + 64u * 24u + (SK_TASKS + 64u) * 2u + SK_QCAP * 8u);
+  u32* cnt = reinterpret_cast<u32*>(reinterpret_cast<char*>(tab + TS) + (size_t)nwaves * SK_WAVE_LDS);
   u32* sc = cnt + P3_NWG;
 #define s_ndist sc[0]
 #define s_cur sc[1]
@@ -205,28 +232,27 @@ __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ par
 #define s_ovf sc[6]
 #define s_nsing sc[7]
 #define s_singbase sc[8]
-  // XCD-aware block -> (bucket, sub-bucket) map: the 2^sbits readers of a bucket get block ids equal mod 8
-  const u32 nsub = 1u << sbits;
+  // XCD-aware block -> (fine bucket, extra sub-bucket) map: the 2^xbits readers of a fine bucket get block ids equal mod 8
+  const u32 nsub = 1u << xbits;
   const u32 grp = blockIdx.x / (8u * nsub), rr = blockIdx.x % (8u * nsub);
-  const u32 pb = grp * 8u + (rr & 7u);
+  const u32 fb = grp * 8u + (rr & 7u);
   const u32 subsel = rr >> 3;
-  const u32 sb = pb * nsub + subsel;
+  const u32 sb = fb * nsub + subsel;
   for (u32 i = threadIdx.x; i < TS; i += blockDim.x) tab[i] = ~0ULL;
   if (threadIdx.x < 16) sc[threadIdx.x] = 0;
-  if (threadIdx.x < P3_NWG) cnt[threadIdx.x] = ghist[pb * P3_NWG + threadIdx.x];
+  if (threadIdx.x < P3_NWG) cnt[threadIdx.x] = ghist[fb * P3_NWG + threadIdx.x];
   __syncthreads();
+  if (dbg & 8u) return;  // (timing experiment: launch + table initialisation only)
   const u32 limit = TS - (TS >> 3);
   const u64 tbase = (u64)sb * TS;
-  const u32 sub_mask = nsub - 1u;
+  const u32 sub_mask = nsub - 1u, sub_shift = 8u + (6u - fbits - xbits);  // the xbits code bits below the fine bucket's
   const unsigned long long lt_mask = (1ULL << lane) - 1;
+  const u32 hshift = 32 - ts_log2;
+  bool guard_hit = false;
 
-  auto slot_of = [&](u64 key) -> u32 {
-    const u32 x = (u32)key ^ __umul24((u32)(key >> 32), 0x9E3779u);
-    return (x * 0x85EBCA6Bu) >> (32 - ts_log2);
-  };
   auto slow_insert = [&](u64 key, u32 pos) {
     const u32 x = (u32)key ^ __umul24((u32)(key >> 32), 0x9E3779u);
-    u32 slot = (x * 0x85EBCA6Bu) >> (32 - ts_log2);
+    u32 slot = (x * 0x85EBCA6Bu) >> hshift;
     const u32 step = ((x * 0xC2B2AE35u) >> 15) | 1u;  // double hashing, odd step
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
@@ -243,7 +269,7 @@ __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ par
         }
       }
       if ((t & SK_MASK42) == key) {
-        if ((u32)(t >> 32) >= SK_CNT_GUARD) s_ovf = 2;
+        guard_hit |= (u32)(t >> 32) >= SK_CNT_GUARD;
         atomicAdd(reinterpret_cast<u32*>(&tab[slot]) + 1, 1u << SK_CNT_SHIFT);
         placed = true;
         break;
@@ -253,104 +279,113 @@ __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ par
     if (!placed) s_ovf = 1;
   };
 
-  SK_FEED_DECL(part + (u64)pb * P3_NWG * segcap);
-  u32 ring_cnt = 0, ring_pos = 0, qn = 0;  // wave-uniform
-  // lane state: rem windows left in the record; window i = len - rem uses shifts that depend on rem only
-  u32 rem = 0, pos_last = 0;
-  u64 lo = 0, rc = 0;
-  for (;;) {
-    const unsigned long long nb = ballot64(rem == 0);
-    if (nb) {
-      while (ring_cnt == 0 && !f_done) {  // refill: accepted records of the next load, compacted
-        const uint4 r = f_nrec;
-        const bool ok = f_nval && (((r.w >> 8) & sub_mask) == subsel);
-        feed_issue();
-        const unsigned long long ab = ballot64(ok);
-        if (ok) ring[__popcll(ab & lt_mask)] = r;
-        ring_cnt = (u32)__popcll(ab);
-        ring_pos = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  SK_FEED_DECL(part + (u64)fb * P3_NWG * segcap);
+  u32 qn = 0;  // wave-uniform
+  bool v_n;
+  u32 nrec_n;
+  const uint4* p_n = feed_round(v_n, nrec_n);
+  uint4 q_n = *p_n;
+  while (nrec_n) {
+    const uint4 rec = q_n;
+    const bool v = v_n;
+    p_n = feed_round(v_n, nrec_n);
+    q_n = *p_n;  // (next round's records: in flight during this round; a lane without one re-reads slot 0)
+    // ---- decode (once per record) -> round buffer; expand -> tasks
+    const bool ok = v && (((rec.w >> sub_shift) & sub_mask) == subsel);
+    const u32 len = ok ? (rec.w & 15u) + 1u : 0u;
+    {
+      const u64 rcw64 = sk_revcomp64(((u64)rec.y << 32) | rec.x);
+      rbA[lane] = make_uint4(rec.x, rec.y, (u32)rcw64, (u32)(rcw64 >> 32));
+      rbB[lane] = make_uint2(rec.z + (rec.w & 15u), len);
+    }
+    u32 off = 0, total = 0;  // exclusive prefix sum of len over the wave from its four bit planes
+#pragma unroll
+    for (int bit = 0; bit < 4; bit++) {
+      const unsigned long long pl = ballot64((len >> bit) & 1u);
+      off += (u32)__popcll(pl & lt_mask) << bit;
+      total += (u32)__popcll(pl) << bit;
+    }
+#pragma unroll
+    for (u32 i = 0; i < SK_LMAX21; i++)
+      tasks[i < len ? off + i : SK_TASKS + lane] = (unsigned short)((lane << 4) | i);  // (idle lanes: trash entries)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (dbg & 1u) continue;  // (timing experiment: feed + decode + expand only)
+    // ---- process: groups of four steps of 64 tasks
+    for (u32 s0 = 0; s0 < total; s0 += 256) {
+      u32 tk[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const u32 q = s0 + 64u * u + lane;
+        tk[u] = tasks[q < total ? q : SK_TASKS + lane];
       }
-      if (ring_cnt) {
-        const u32 rank = (u32)__popcll(nb & lt_mask);
-        if (rem == 0 && rank < ring_cnt) {
-          const uint4 r = ring[ring_pos + rank];
-          lo = ((u64)r.y << 32) | r.x;
-          rc = sk_revcomp64(lo);
-          rem = (r.w & 15u) + 1u;
-          pos_last = r.z + (r.w & 15u);
+      uint4 a[4];
+      uint2 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const u32 e = (tk[u] >> 4) & 63u;
+        a[u] = rbA[e];
+        b[u] = rbB[e];
+      }
+      u64 key[4];
+      u32 slot[4], rm1[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        // window i of the record: rm1 = len - 1 - i windows follow it.  forward = bits [2 rm1, 2 rm1 + 42) of the
+        // bases, reverse complement = bits [2 (11 - rm1), ...) of the word's reverse complement
+        rm1[u] = (b[u].y - 1u - (tk[u] & 15u)) & 15u;
+        const u64 f = ((((u64)a[u].y << 32) | a[u].x) >> (2u * rm1[u])) & SK_MASK42;
+        const u64 r = ((((u64)a[u].w << 32) | a[u].z) >> ((22u - 2u * rm1[u]) & 63u)) & SK_MASK42;
+        key[u] = f <= r ? f : r;
+        const u32 x = (u32)key[u] ^ __umul24((u32)(key[u] >> 32), 0x9E3779u);
+        slot[u] = (x * 0x85EBCA6Bu) >> hshift;
+      }
+      u64 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[u] = tab[slot[u]];
+      bool miss[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool active = s0 + 64u * u + lane < total;
+        const bool hit = active && (t[u] & SK_MASK42) == key[u];
+        guard_hit |= hit && (u32)(t[u] >> 32) >= SK_CNT_GUARD;
+        atomicAdd(reinterpret_cast<u32*>(&tab[slot[u]]) + 1, hit ? (1u << SK_CNT_SHIFT) : 0u);  // (+0: no branch)
+        miss[u] = active && !hit;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned long long mb = ballot64(miss[u]);
+        if (mb) {
+          if (miss[u]) {
+            const u32 qi = qn + (u32)__popcll(mb & lt_mask);
+            qkey[qi] = key[u];
+            qpos[qi] = b[u].x - rm1[u];
+          }
+          qn += (u32)__popcll(mb);
+          if (qn >= 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qn -= 64;
+            slow_insert(qkey[qn + lane], qpos[qn + lane]);
+          }
         }
-        const u32 want = (u32)__popcll(nb);
-        const u32 took = want < ring_cnt ? want : ring_cnt;
-        ring_pos += took;
-        ring_cnt -= took;
-        __builtin_amdgcn_wave_barrier();
       }
     }
-    const bool active = rem != 0;
-    if (!ballot64(active)) {
-      if (f_done && ring_cnt == 0) break;
-      continue;
-    }
-    // window i = len - rem of the record: forward = bits [2 (rem - 1), 2 (rem - 1) + 42) of lo, reverse complement =
-    // bits [2 (12 - rem), ...) of the word's reverse complement
-    const u32 rm1 = active ? rem - 1u : 0u;
-    const u64 f = (lo >> (2u * rm1)) & SK_MASK42;
-    const u64 r = (rc >> (2u * (11u - rm1))) & SK_MASK42;
-    const u64 key = f <= r ? f : r;
-    const u32 slot = slot_of(key);
-    const u64 t = tab[slot];
-    const bool hit = active && (t & SK_MASK42) == key;
-    if (hit) {
-      if ((u32)(t >> 32) >= SK_CNT_GUARD) s_ovf = 2;
-      atomicAdd(reinterpret_cast<u32*>(&tab[slot]) + 1, 1u << SK_CNT_SHIFT);
-    }
-    const bool miss = active && !hit;
-    const unsigned long long mb = ballot64(miss);
-    if (miss) {
-      const u32 qi = qn + (u32)__popcll(mb & lt_mask);
-      qkey[qi] = key;
-      qpos[qi] = pos_last - rm1;
-    }
-    qn += (u32)__popcll(mb);
-    rem = rm1;  // (inactive lanes stay at 0)
-    if (qn >= 64) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      qn -= 64;
-      slow_insert(qkey[qn + lane], qpos[qn + lane]);
-    }
+    __builtin_amdgcn_wave_barrier();  // (the round buffer and the tasks are rewritten next)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < qn) slow_insert(qkey[lane], qpos[lane]);
+  if (guard_hit) s_ovf = 2;
+  if (dbg & 2u) return;  // (timing experiment: no emission)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (s_ovf) atomicMax((unsigned long long*)&gstats[3], (unsigned long long)s_ovf);
-    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)s_ndist);
-    s_base_lo = (u32)base;
-    s_base_hi = (u32)(base >> 32);
-  }
-  __syncthreads();
-  const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
-  if (base + s_ndist > gstats[30]) {  // outputs hold gstats[30] entries
-    if (threadIdx.x == 0) gstats[31] = 1;
-    return;
-  }
+  // ---- emission.  One pass over the table for the statistics, then BOTH global cursors are advanced at once (one
+  // round trip instead of two), the first-instance pairs being fetched meanwhile.
+  const u32 nd = s_ndist;
   u32 my_solid = 0, my_max = 0, my_single = 0;
-  for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
-    const u32 i = i0 + threadIdx.x;
-    const u64 t = (i < TS) ? tab[i] : ~0ULL;
-    const bool full = t != ~0ULL;
-    const unsigned long long bal = ballot64(full);
-    u32 wbase = 0;
-    if (lane == 0 && bal) wbase = atomicAdd(&s_cur, (u32)__popcll(bal));
-    wbase = __shfl(wbase, 0, 64);
-    if (full) {
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) {
+    const u64 t = tab[i];
+    if (t != ~0ULL) {
       const u32 c = (u32)(t >> 32) >> SK_CNT_SHIFT;
-      const u32 idx = wbase + (u32)__popcll(bal & lt_mask);
-      out_keys[base + idx] = t & SK_MASK42;
-      out_counts[base + idx] = c;
       my_solid += (c >= 2);
       my_max = c > my_max ? c : my_max;
       my_single += (c == 1);
@@ -367,30 +402,70 @@ __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ par
     if (my_solid) atomicAdd(&s_nsolid, my_solid);
     if (my_max) atomicMax(&s_max, my_max);
   }
+  constexpr u32 NPAIR = 8;  // pairs per thread held in registers; any further ones are read when they are used
+  u64 pr[NPAIR];
+#pragma unroll
+  for (u32 j = 0; j < NPAIR; j++) {
+    const u32 t = j * blockDim.x + threadIdx.x;
+    pr[j] = t < nd ? tpairs[tbase + t] : 0;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (s_ovf) atomicMax((unsigned long long*)&gstats[3], (unsigned long long)s_ovf);
+    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)nd);
+    s_base_lo = (u32)base;
+    s_base_hi = (u32)(base >> 32);
+  }
+  if (threadIdx.x == 64) {
     const u32 n = s_nsing;
     s_singbase = n ? (u32)atomicAdd((unsigned long long*)&sing_cursor[0], (unsigned long long)n) : 0u;
-    s_nsing = 0;
   }
   __syncthreads();
-  const u32 nd = s_ndist;
-  for (u32 t0 = 0; t0 < nd; t0 += blockDim.x) {  // positions of the single-instance keys: one LDS atomic per wave
-    const u32 t = t0 + threadIdx.x;
-    u64 pr = 0;
-    bool one = false;
-    if (t < nd) {
-      pr = tpairs[tbase + t];
-      one = ((u32)(tab[(u32)(pr >> 32) & (TS - 1)] >> 32) >> SK_CNT_SHIFT) == 1u;
+  const u64 base = ((u64)s_base_hi << 32) | s_base_lo;
+  if (base + nd > out_cap) {  // outputs too small: the host repeats the stage with larger ones
+    if (threadIdx.x == 0) gstats[31] = 1;
+    return;
+  }
+  for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
+    const u32 i = i0 + threadIdx.x;
+    const u64 t = (i < TS) ? tab[i] : ~0ULL;
+    const bool full = t != ~0ULL;
+    const unsigned long long bal = ballot64(full);
+    u32 wbase_i = 0;
+    if (lane == 0 && bal) wbase_i = atomicAdd(&s_cur, (u32)__popcll(bal));
+    wbase_i = __shfl(wbase_i, 0, 64);
+    if (full) {
+      const u32 idx = wbase_i + (u32)__popcll(bal & lt_mask);
+      out_keys[base + idx] = t & SK_MASK42;
+      out_counts[base + idx] = (u32)(t >> 32) >> SK_CNT_SHIFT;
     }
+  }
+  // positions of the single-instance keys (one LDS atomic per wave; s_cur is reused as the list cursor)
+  __syncthreads();
+  if (threadIdx.x == 0) s_cur = 0;
+  __syncthreads();
+#pragma unroll
+  for (u32 j = 0; j < NPAIR; j++) {
+    const u32 t = j * blockDim.x + threadIdx.x;
+    const bool one = t < nd && ((u32)(tab[(u32)(pr[j] >> 32) & (TS - 1)] >> 32) >> SK_CNT_SHIFT) == 1u;
     const unsigned long long bal = ballot64(one);
-    u32 wbase = 0;
-    if (lane == 0 && bal) wbase = atomicAdd(&s_nsing, (u32)__popcll(bal));
-    wbase = __shfl(wbase, 0, 64);
-    if (one) singles[s_singbase + wbase + (u32)__popcll(bal & lt_mask)] = (u32)pr;
+    u32 wbase_i = 0;
+    if (lane == 0 && bal) wbase_i = atomicAdd(&s_cur, (u32)__popcll(bal));
+    wbase_i = __shfl(wbase_i, 0, 64);
+    if (one) singles[s_singbase + wbase_i + (u32)__popcll(bal & lt_mask)] = (u32)pr[j];
+  }
+  for (u32 t0 = NPAIR * blockDim.x; t0 < nd; t0 += blockDim.x) {
+    const u32 t = t0 + threadIdx.x;
+    const u64 p1 = t < nd ? tpairs[tbase + t] : 0;
+    const bool one = t < nd && ((u32)(tab[(u32)(p1 >> 32) & (TS - 1)] >> 32) >> SK_CNT_SHIFT) == 1u;
+    const unsigned long long bal = ballot64(one);
+    u32 wbase_i = 0;
+    if (lane == 0 && bal) wbase_i = atomicAdd(&s_cur, (u32)__popcll(bal));
+    wbase_i = __shfl(wbase_i, 0, 64);
+    if (one) singles[s_singbase + wbase_i + (u32)__popcll(bal & lt_mask)] = (u32)p1;
   }
   if (threadIdx.x == 0) {
-    sb_info[sb] = make_uint4((u32)base, s_ndist, s_nsolid, (u32)(base >> 32));
+    sb_info[sb] = make_uint4((u32)base, nd, s_nsolid, (u32)(base >> 32));
     if (s_nsolid) {
       atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)s_nsolid);
       atomicMax((unsigned long long*)&gstats[4], (unsigned long long)s_nsolid);
@@ -422,11 +497,13 @@ __device__ __forceinline__ void sk_combine(const u32 (&A)[32 + 15], u32 (&sig)[3
 __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                  const u32* __restrict__ endm, u32* __restrict__ P,
                                                                  const u32* __restrict__ S, u64 n_words, u32 k,
-                                                                 uint4* __restrict__ part, SkSeg seg,
+                                                                 uint4* __restrict__ part, SkSeg seg, u32 fbits,
                                                                  u64* __restrict__ stats) {
-  __shared__ u32 cursor[P3_NB];
-  __shared__ u32 s_tot[2];
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) cursor[i] = 0;
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 NF = P3_NB << fbits, cshift = 6u - fbits;
+  u32* cursor = lds;
+  u32* s_tot = lds + NF;
+  for (u32 i = threadIdx.x; i < NF; i += blockDim.x) cursor[i] = 0;
   if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
   __syncthreads();
   u64 begin, end;
@@ -503,7 +580,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __re
           vhi = W[0] >> s;
         }
         const u32 code = sk_code(sig[j]);
-        const u32 b = code >> 6;
+        const u32 b = code >> cshift;
         const u64 rlo = (vlo << 12) | ((code & 63u) << 5) | (len - 1u);
         const u64 rhi = (vhi << 12) | (vlo >> 52);
         const u32 ticket = atomicAdd(&cursor[b], 1u);
@@ -525,7 +602,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __re
     if (n_pass) atomicAdd(&s_tot[1], n_pass);
   }
   __syncthreads();
-  for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) {
+  for (u32 i = threadIdx.x; i < NF; i += blockDim.x) {
     const u32 n = cursor[i];
     seg.ghist_out[i * P3_NWG + blockIdx.x] = n < seg.segcap ? n : seg.segcap;
   }
@@ -536,35 +613,48 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __re
 }
 
 // ---- k_sk_dedup (k <= 32) -------------------------------------------------------------------------------------------------
-// gstats[0] = distinct cursor, gstats[3] = overflow flag (as k_kmer_dedup).
-// LDS: table u64[TS] | ring uint4[nwaves][64] | qkey u64[nwaves][128] | cnt u32[256] | scalars
+// gstats[0] = distinct cursor, gstats[3] = overflow flag (as k_kmer_dedup).  Same round structure as k_sk_count; a round's
+// 64 records are expanded and processed in two halves of 32 (a record holds up to 32 windows).
+// LDS: table u64[TS] | per wave: rbA, rbB uint4[64] (bases right-aligned + windows | reverse complement),
+//      tasks u16[1024 + 64], qkey u64[128] | cnt u32[256] | scalars
+#define SK_DTASKS 1024u
+#define SK_DWAVE_LDS (64u * 32u + (SK_DTASKS + 64u) * 2u + SK_QCAP * 8u)
+__device__ __forceinline__ u64 sk_shr128(u64 lo, u64 hi, u32 s) {  // bits [s, s + 64) of hi:lo, 0 <= s < 128
+  const u32 sh = s & 63u;
+  const u64 a = s < 64u ? lo : hi, b = s < 64u ? hi : 0ULL;
+  return sh ? ((a >> sh) | (b << (64u - sh))) : a;
+}
 __global__ void __launch_bounds__(1024) k_sk_dedup(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
-                                                   u32 sbits, u32 ts_log2, u32 k, u64* __restrict__ out_keys,
+                                                   u32 fbits, u32 xbits, u32 ts_log2, u32 k, u64* __restrict__ out_keys,
                                                    u64* __restrict__ gstats) {
   extern __shared__ __align__(16) u32 lds[];
   const u32 TS = 1u << ts_log2;
   const u32 nwaves = blockDim.x >> 6, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   u64* tab = reinterpret_cast<u64*>(lds);
-  uint4* ring = reinterpret_cast<uint4*>(tab + TS) + wave * 64;
-  u64* qkey = reinterpret_cast<u64*>(reinterpret_cast<uint4*>(tab + TS) + nwaves * 64) + wave * SK_QCAP;
-  u32* cnt = reinterpret_cast<u32*>(reinterpret_cast<u64*>(reinterpret_cast<uint4*>(tab + TS) + nwaves * 64) + nwaves * SK_QCAP);
+  char* wbase = reinterpret_cast<char*>(tab + TS) + (size_t)wave * SK_DWAVE_LDS;
+  uint4* rbA = reinterpret_cast<uint4*>(wbase);
+  uint4* rbB = reinterpret_cast<uint4*>(wbase + 64u * 16u);
+  unsigned short* tasks = reinterpret_cast<unsigned short*>(wbase + 64u * 32u);
+  u64* qkey = reinterpret_cast<u64*>(wbase + 64u * 32u + (SK_DTASKS + 64u) * 2u);
+  u32* cnt = reinterpret_cast<u32*>(reinterpret_cast<char*>(tab + TS) + (size_t)nwaves * SK_DWAVE_LDS);
   u32* sc = cnt + P3_NWG;
-  const u32 nsub = 1u << sbits;
+  const u32 nsub = 1u << xbits;
   const u32 grp = blockIdx.x / (8u * nsub), rr = blockIdx.x % (8u * nsub);
-  const u32 pb = grp * 8u + (rr & 7u);
+  const u32 fb = grp * 8u + (rr & 7u);
   const u32 subsel = rr >> 3;
   for (u32 i = threadIdx.x; i < TS; i += blockDim.x) tab[i] = ~0ULL;
   if (threadIdx.x < 16) sc[threadIdx.x] = 0;
-  if (threadIdx.x < P3_NWG) cnt[threadIdx.x] = ghist[pb * P3_NWG + threadIdx.x];
+  if (threadIdx.x < P3_NWG) cnt[threadIdx.x] = ghist[fb * P3_NWG + threadIdx.x];
   __syncthreads();
   const u32 limit = TS - (TS >> 3);
-  const u32 sub_mask = nsub - 1u;
+  const u32 sub_mask = nsub - 1u, sub_shift = 5u + (6u - fbits - xbits);
   const unsigned long long lt_mask = (1ULL << lane) - 1;
   const u64 kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const u32 hshift = 32 - ts_log2;
   auto hash_of = [&](u64 key) -> u32 { return (u32)key ^ ((u32)(key >> 32) * 0x85EBCA6Bu); };
   auto slow_insert = [&](u64 key) {
     const u32 x = hash_of(key);
-    u32 slot = (x * 0x2C1B3C6Du) >> (32 - ts_log2);
+    u32 slot = (x * 0x2C1B3C6Du) >> hshift;
     const u32 step = ((x * 0xC2B2AE35u) >> 15) | 1u;
     bool placed = false;
     for (u32 probes = 0; probes < TS; probes++) {
@@ -586,75 +676,93 @@ __global__ void __launch_bounds__(1024) k_sk_dedup(const uint4* __restrict__ par
     }
     if (!placed) sc[6] = 1;
   };
-  SK_FEED_DECL(part + (u64)pb * P3_NWG * segcap);
-  u32 ring_cnt = 0, ring_pos = 0, qn = 0;
-  // lane state: V = the record's bases, right-aligned (vhi:vlo), rcl/rch = reverse complement of the low 64 / high
-  // bases; window i = len - rem: forward = V >> 2 (rem - 1); reverse complement built from the two halves
-  u32 rem = 0;
-  u64 vlo = 0, vhi = 0, rlo = 0, rhi = 0;
-  for (;;) {
-    const unsigned long long nb = ballot64(rem == 0);
-    if (nb) {
-      while (ring_cnt == 0 && !f_done) {
-        const uint4 r = f_nrec;
-        const bool ok = f_nval && (((r.x >> 5) & sub_mask) == subsel);
-        feed_issue();
-        const unsigned long long ab = ballot64(ok);
-        if (ok) ring[__popcll(ab & lt_mask)] = r;
-        ring_cnt = (u32)__popcll(ab);
-        ring_pos = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  SK_FEED_DECL(part + (u64)fb * P3_NWG * segcap);
+  u32 qn = 0;
+  bool v_n;
+  u32 nrec_n;
+  const uint4* p_n = feed_round(v_n, nrec_n);
+  uint4 q_n = *p_n;
+  while (nrec_n) {
+    const uint4 rec = q_n;
+    const bool v = v_n;
+    p_n = feed_round(v_n, nrec_n);
+    q_n = *p_n;
+    const bool ok = v && (((rec.x >> sub_shift) & sub_mask) == subsel);
+    const u32 len = ok ? (rec.x & 31u) + 1u : 0u;  // 1..32
+    {
+      const u64 a = ((u64)rec.y << 32) | rec.x, b = ((u64)rec.w << 32) | rec.z;
+      const u64 vlo = (a >> 12) | (b << 52), vhi = b >> 12;  // V = the record's bases, right-aligned (vhi < 2^52)
+      // reverse complement of the 64-base string vhi:vlo (MSB-first) = revcomp(vlo) : revcomp(vhi)
+      const u64 rhi = sk_revcomp64(vlo), rlo = sk_revcomp64(vhi);
+      rbA[lane] = make_uint4((u32)vlo, (u32)(vlo >> 32), (u32)vhi, (u32)(vhi >> 32) | (len << 24));
+      rbB[lane] = make_uint4((u32)rlo, (u32)(rlo >> 32), (u32)rhi, (u32)(rhi >> 32));
+    }
+    for (u32 half = 0; half < 2; half++) {
+      const u32 hl = (lane >> 5) == half ? len : 0u;
+      u32 off = 0, total = 0;
+#pragma unroll
+      for (int bit = 0; bit < 6; bit++) {
+        const unsigned long long pl = ballot64((hl >> bit) & 1u);
+        off += (u32)__popcll(pl & lt_mask) << bit;
+        total += (u32)__popcll(pl) << bit;
       }
-      if (ring_cnt) {
-        const u32 rank = (u32)__popcll(nb & lt_mask);
-        if (rem == 0 && rank < ring_cnt) {
-          const uint4 r = ring[ring_pos + rank];
-          const u64 a = ((u64)r.y << 32) | r.x, b = ((u64)r.w << 32) | r.z;
-          rem = (r.x & 31u) + 1u;
-          vlo = (a >> 12) | (b << 52);
-          vhi = b >> 12;
-          // reverse complement of the 128-bit base string vhi:vlo (64 bases, MSB-first): rc = revcomp(vlo):revcomp(vhi)
-          rhi = sk_revcomp64(vlo);
-          rlo = sk_revcomp64(vhi);
+      if (total == 0) continue;
+      __builtin_amdgcn_wave_barrier();  // (the previous half's task reads are done)
+#pragma unroll 8
+      for (u32 i = 0; i < 32; i++)
+        tasks[i < hl ? off + i : SK_DTASKS + lane] = (unsigned short)((lane << 5) | i);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (u32 s0 = 0; s0 < total; s0 += 256) {
+        u32 tk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const u32 q = s0 + 64u * u + lane;
+          tk[u] = tasks[q < total ? q : SK_DTASKS + lane];
         }
-        const u32 want = (u32)__popcll(nb);
-        const u32 took = want < ring_cnt ? want : ring_cnt;
-        ring_pos += took;
-        ring_cnt -= took;
-        __builtin_amdgcn_wave_barrier();
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const u32 e = (tk[u] >> 5) & 63u;
+          a[u] = rbA[e];
+          b[u] = rbB[e];
+        }
+        u64 key[4];
+        u32 slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          // window i of the record: rm1 = len - 1 - i windows follow it; the window ends 2 rm1 bits above V's right end.
+          // Its reverse complement: base slots [rm1, rm1 + k) of the reversed 64-base string = bits
+          // [128 - 2 (rm1 + k), 128 - 2 rm1) of rhi:rlo
+          const u32 rm1 = ((a[u].w >> 24) - 1u - (tk[u] & 31u)) & 31u;
+          const u64 vlo = ((u64)a[u].y << 32) | a[u].x, vhi = ((u64)(a[u].w & 0x00ffffffu) << 32) | a[u].z;
+          const u64 rlo = ((u64)b[u].y << 32) | b[u].x, rhi = ((u64)b[u].w << 32) | b[u].z;
+          const u64 f = sk_shr128(vlo, vhi, 2u * rm1) & kmask;
+          const u64 r = sk_shr128(rlo, rhi, 128u - 2u * (rm1 + k)) & kmask;
+          key[u] = f <= r ? f : r;
+          slot[u] = (hash_of(key[u]) * 0x2C1B3C6Du) >> hshift;
+        }
+        u64 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) t[u] = tab[slot[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool miss = (s0 + 64u * u + lane < total) && t[u] != key[u];
+          const unsigned long long mb = ballot64(miss);
+          if (mb) {
+            if (miss) qkey[qn + (u32)__popcll(mb & lt_mask)] = key[u];
+            qn += (u32)__popcll(mb);
+            if (qn >= 64) {
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              qn -= 64;
+              slow_insert(qkey[qn + lane]);
+            }
+          }
+        }
       }
     }
-    const bool active = rem != 0;
-    if (!ballot64(active)) {
-      if (f_done && ring_cnt == 0) break;
-      continue;
-    }
-    const u32 rm1 = active ? rem - 1u : 0u;
-    // forward k-mer of the window that ends 2 rm1 bits above the right end
-    const u32 sa = 2u * rm1;  // 0..62
-    const u64 f = (sa ? ((vlo >> sa) | (vhi << (64 - sa))) : vlo) & kmask;
-    // its reverse complement: the window covers base slots [64 - k - rm1, 64 - rm1) of the 64-base string V; in the
-    // reversed string those are slots [rm1, rm1 + k): bits [128 - 2 (rm1 + k), 128 - 2 rm1) of rhi:rlo
-    const u32 sb2 = 128u - 2u * (rm1 + k);  // >= 2
-    u64 r;
-    if (sb2 >= 64) r = rhi >> (sb2 - 64);
-    else r = (rlo >> sb2) | (rhi << (64 - sb2));
-    r &= kmask;
-    const u64 key = f <= r ? f : r;
-    const u32 slot = (hash_of(key) * 0x2C1B3C6Du) >> (32 - ts_log2);
-    const u64 t = tab[slot];
-    const bool miss = active && t != key;
-    const unsigned long long mb = ballot64(miss);
-    if (miss) qkey[qn + (u32)__popcll(mb & lt_mask)] = key;
-    qn += (u32)__popcll(mb);
-    rem = rm1;
-    if (qn >= 64) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      qn -= 64;
-      slow_insert(qkey[qn + lane]);
-    }
+    __builtin_amdgcn_wave_barrier();  // (the round buffer and the tasks are rewritten next)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (lane < qn) slow_insert(qkey[lane]);
@@ -672,9 +780,9 @@ __global__ void __launch_bounds__(1024) k_sk_dedup(const uint4* __restrict__ par
     const u64 t = (i < TS) ? tab[i] : ~0ULL;
     const bool full = t != ~0ULL;
     const unsigned long long bal = ballot64(full);
-    u32 wbase = 0;
-    if (lane == 0 && bal) wbase = atomicAdd(&sc[1], (u32)__popcll(bal));
-    wbase = __shfl(wbase, 0, 64);
-    if (full) out_keys[base + wbase + (u32)__popcll(bal & lt_mask)] = t;
+    u32 wbase_i = 0;
+    if (lane == 0 && bal) wbase_i = atomicAdd(&sc[1], (u32)__popcll(bal));
+    wbase_i = __shfl(wbase_i, 0, 64);
+    if (full) out_keys[base + wbase_i + (u32)__popcll(bal & lt_mask)] = t;
   }
 }

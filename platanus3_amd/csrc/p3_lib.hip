@@ -182,13 +182,17 @@ struct p3_ctx {
   // run-length ("super-k-mer") records, p3_kernels_sk.h: the partition stages move one 16-byte record per RUN of
   // windows.  sk_opt: 0 = automatic, 1 = never, 2 = wherever the form applies (tests).  sk_ok is cleared, until new
   // reads arrive, when the form turned out not to fit the input (unknown bases, a capacity that overflowed twice, a
-  // count that outgrew the 22-bit slot field): the per-window kernels then take over.
+  // count that outgrew the 22-bit slot field): the per-window kernels then take over.  Off unless asked for: it
+  // measured slower than the per-window kernels (see sk_on).
   int sk_opt = 0;
   bool sk_ok = true;
   u32 sk_boost = 0;          // 0 = expected run density, 1 = one record per window (worst case)
   bool part_sk = false;      // the current count partition holds run records (16 B)
   bool kpart_sk = false;     // ... and so does the current k-mer partition
   u32 sk_segcap = 0, sk_ksegcap = 0;
+  u32 sk_fbits = 0, sk_kfbits = 0;  // sub-bucket bits the scatter turned into separate segments (fine buckets)
+  int sk_dbg = 0;            // timing experiments (results are wrong when non-zero)
+  int sk_waves_opt = 16;     // waves per workgroup of the run-record consumers (4..16)
   int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
   DevBuf unk_flag;           // set by k_pack when a base is not A/C/G/T
 
@@ -521,20 +525,20 @@ double active_wgs(u64 n_words);
 // ---- run-length records (p3_kernels_sk.h): when the form is used ----------------------------------------------------
 // One rank, one position range, estimated capacities, none of the test options that select a particular per-window
 // path, and reads without unknown bases (known after the first k_pack over them: sk_ok).
+constexpr u32 SK_FBITS_MAX = 5;  // 32 Ki cursors = 128 KiB of LDS in the scatter kernels
 bool sk_on(const p3_ctx* c) {
-  if (c->sk_opt == 1 || !c->sk_ok) return false;
-  if (!est_mode(c) || c->chunks != 1 || c->n_words * 32 > (1ull << 30)) return false;
-  if (c->sk_opt == 2) return true;
-  return c->count_mode_opt == 0 && c->gate_mode_opt == 0 && c->bloom_mode_opt == 0 && c->split_opt == 0 &&
-         c->ksplit_opt == 0 && c->dbg_opt == 0 && c->ts_log2_opt == P3_TS_LOG2_MAX && c->tsk_log2_opt == 14 &&
-         c->chunk_opt == 0 && c->est_boost == 0;
+  // Measured on MI355X (profiles/r02_sk_*): the record form moves 3x fewer bytes but its consumers are bound by
+  // instruction issue and LDS latency, not by HBM -- 2.85 ms per config-#2 pass against 2.6 ms for the per-window
+  // kernels -- so it is used only when asked for (run_records = 2).
+  if (c->sk_opt != 2 || !c->sk_ok) return false;
+  return est_mode(c) && c->chunks == 1 && c->n_words * 32 <= (1ull << 30);
 }
 // records per (bucket, workgroup) segment for `windows` windows cut into runs: a run ends where the minimizer changes
 // (every (w + 1) / 2 windows for random sequence, w = m-mers per k-mer), at the word boundary (1 / 32) and at a read
 // end; buckets of minimizers are less even than buckets of hashed keys (+25 %).  sk_boost = 1: one record per window.
-u32 sk_segcap_for(const p3_ctx* c, double windows, u32 w_mmers) {
-  const double per_window = c->sk_boost ? 1.0 : (2.0 / (w_mmers + 1) + 1.0 / 32 + 1.0 / 100) * 1.25;
-  const double mean = windows * per_window / ((double)P3_NB * active_wgs(c->n_words));
+u32 sk_segcap_for(const p3_ctx* c, double windows, u32 w_mmers, u32 fbits) {
+  const double per_window = c->sk_boost ? 1.0 : (2.0 / (w_mmers + 1) + 1.0 / 32 + 1.0 / 100) * (fbits ? 1.35 : 1.25);
+  const double mean = windows * per_window / ((double)(P3_NB << fbits) * active_wgs(c->n_words));
   return ((u32)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15u) & ~15u;
 }
 // the run-record form did not fit (a full segment, a count beyond the slot field, unknown bases): next level or off
@@ -610,12 +614,20 @@ int part_local(p3_ctx* c, bool with_pos) {
   if (est && sk_on(c)) {
     // run-length records: one 16-byte record per run of windows, written straight into fixed-stride segments
     const double windows = c->host_windows ? (double)c->host_windows : (double)c->n_words * 32;
-    const u32 cap = sk_segcap_for(c, windows, SK_W21);
-    if ((rc = ensure(c, c->part8, (u64)P3_NB * P3_NWG * cap * 16))) return rc;
-    LAUNCH(c, "k_sk_scatter21", k_sk_scatter21, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-           (const u32*)c->endm.p, c->n_words, (uint4*)c->part8.p, (SkSeg{cap, (u32*)c->ghist.p, st + 26}), st + 5);
+    // fine buckets: as many of the sub-bucket bits as the count is expected to need (every consumer workgroup then
+    // reads exactly what it counts); further splits, should a table still overflow, filter inside a fine bucket
+    u32 sb = c->spec ? c->hint_sbits : sk_initial_sbits(c->host_windows ? c->host_windows : c->n_words * 32, (u32)c->sk_ts_log2_opt);
+    if (!c->spec && c->sbits_epoch == c->reads_epoch && c->sbits_sk > sb) sb = c->sbits_sk;
+    const u32 fbits = sb < SK_FBITS_MAX ? sb : SK_FBITS_MAX;
+    const u32 cap = sk_segcap_for(c, windows, SK_W21, fbits);
+    if ((rc = ensure(c, c->ghist, ((size_t)P3_NB << fbits) * P3_NWG * 4))) return rc;
+    if ((rc = ensure(c, c->part8, ((u64)P3_NB << fbits) * P3_NWG * cap * 16))) return rc;
+    LAUNCH_LDS(c, "k_sk_scatter21", k_sk_scatter21, P3_NWG, P3_PART_THREADS, ((size_t)(P3_NB << fbits) + 4) * 4, (const u64*)c->fw.p,
+               (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (uint4*)c->part8.p,
+               (SkSeg{cap, (u32*)c->ghist.p, st + 26}), fbits, st + 5);
     c->part_sk = true;
     c->sk_segcap = cap;
+    c->sk_fbits = fbits;
   } else if (est) {
     // no histogram pass and no scan: fixed-stride segments; the scatter reports what it wrote
     if ((rc = fixed_segoff(c, segcap))) return rc;
@@ -739,14 +751,16 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
   const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
   if (c->part_sk) {
+    if (sbits < c->sk_fbits) return fail(c, P3_EHIP, "run records: split %u below the scattered fine buckets %u", sbits, c->sk_fbits);
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
     HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
-    const u32 nwaves = 16;
-    const size_t lds = ((size_t)8 << ts_log2) + nwaves * (64 * 16 + SK_QCAP * 12) + P3_NWG * 4 + 64;
-    LAUNCH_LDS(c, "k_sk_count", k_sk_count, nsb, nwaves * 64, lds, (const uint4*)kpart, (const u32*)khist, c->sk_segcap, sbits,
-               ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-               (u64*)c->sing_cursor.p);
+    const u32 nwaves = (u32)c->sk_waves_opt;
+    const size_t lds = ((size_t)8 << ts_log2) + nwaves * SK_WAVE_LDS + P3_NWG * 4 + 64;
+    if (lds > 160u * 1024u) return fail(c, P3_EBADARG, "run-record count: %zu bytes of LDS (sk_ts_log2 / sk_waves)", lds);
+    LAUNCH_LDS(c, "k_sk_count", k_sk_count, nsb, nwaves * 64, lds, (const uint4*)kpart, (const u32*)khist, c->sk_segcap,
+               c->sk_fbits, sbits - c->sk_fbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
+               (u64*)c->sing_cursor.p, maxd, (u32)c->sk_dbg);
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
   } else if (c->part_pos) {
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;  // (src|slot|pos) per first instance
@@ -1093,6 +1107,7 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
   if (c->part_sk) {
     first = sk_initial_sbits(c->host_windows ? c->host_windows : c->n_words * 32, (u32)c->sk_ts_log2_opt);
     if (c->sbits_epoch == c->reads_epoch && c->sbits_sk > first) first = c->sbits_sk;  // what the last pass needed
+    if (first < c->sk_fbits) first = c->sk_fbits;
   } else if (with_pos && c->part_est && c->split_opt != 1) {
     if (c->split_opt >= 2) c->split_xbits = (u32)c->split_opt - 1;
     else if (first >= 3) c->split_xbits = first;
@@ -1352,10 +1367,16 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (sk_k) {
       const double kwin = c->pass_hint && c->pass_hint_k == k ? (double)c->pass_hint * 1.02
                           : c->host_windows ? (double)c->host_windows : (double)c->n_words * 32;
-      segcap_k = sk_segcap_for(c, kwin, k - SK_M + 1) * 2;  // (16-byte records in a buffer of 8-byte REC)
-      c->sk_ksegcap = segcap_k / 2;
+      // fine buckets for the sub-bucket split the k-mer sets are expected to need (as in part_local)
+      u32 sbk = 0;
+      for (; sbk < 6 && (c->n_words * 32) / ((u64)P3_NB << sbk) > (8ull << c->sk_ts_log2_opt); sbk++) {}
+      if (c->spec) sbk = c->hint_ksbits;
+      else if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k && !c->kxg && c->ksbits > sbk && c->ksbits <= 6) sbk = c->ksbits;
+      c->sk_kfbits = sbk < SK_FBITS_MAX ? sbk : SK_FBITS_MAX;
+      c->sk_ksegcap = sk_segcap_for(c, kwin, k - SK_M + 1, c->sk_kfbits);
+      segcap_k = (c->sk_ksegcap * 2) << c->sk_kfbits;  // (16-byte records, 1024 << fbits buckets, in a buffer of 8-byte REC)
     }
-    if ((rc = ensure(c, c->ghist, (size_t)P3_NB * P3_NWG * 4))) return rc;
+    if ((rc = ensure(c, c->ghist, ((size_t)P3_NB << (sk_k ? c->sk_kfbits : 0u)) * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
     if ((rc = ensure(c, c->kpart, (est ? (u64)P3_NB * P3_NWG * segcap_k : max_records) * sizeof(REC)))) return rc;
@@ -1369,9 +1390,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                  (REC*)c->kpart.p, (EstSeg{segcap_k, (u32*)c->ghist.p, st + 27}));
     } else if (sk_k) {
       HIPCHK(c, hipMemsetAsync(st + 28, 0, 8, c->stream));
-      LAUNCH(c, "k_sk_kscatter", k_sk_kscatter, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-             (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k, (uint4*)c->kpart.p,
-             (SkSeg{c->sk_ksegcap, (u32*)c->ghist.p, st + 28}), st + 8);
+      LAUNCH_LDS(c, "k_sk_kscatter", k_sk_kscatter, P3_NWG, P3_PART_THREADS, ((size_t)(P3_NB << c->sk_kfbits) + 4) * 4,
+                 (const u64*)c->fw.p, (const u64*)c->rcw.p, (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k,
+                 (uint4*)c->kpart.p, (SkSeg{c->sk_ksegcap, (u32*)c->ghist.p, st + 28}), c->sk_kfbits, st + 8);
       c->kpart_sk = true;
     } else if (est) {
       // estimated segment capacities: the scatter evaluates the gate itself (P, statistics) -- no histogram pass
@@ -1401,10 +1422,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     auto dedup_once = [&](u32 sb, u32 xg) -> int {
       HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
       if (c->kpart_sk) {
-        const u32 nwaves = 16;
-        const size_t lds_sk = ((size_t)8 << ts_log2) + nwaves * (64 * 16 + SK_QCAP * 8) + P3_NWG * 4 + 64;
+        const u32 nwaves = (u32)c->sk_waves_opt;
+        const size_t lds_sk = ((size_t)8 << ts_log2) + nwaves * SK_DWAVE_LDS + P3_NWG * 4 + 64;
+        if (lds_sk > 160u * 1024u) return fail(c, P3_EBADARG, "run-record dedup: %zu bytes of LDS (sk_ts_log2 / sk_waves)", lds_sk);
+        if (sb < c->sk_kfbits) return fail(c, P3_EHIP, "run records: k-mer split %u below the scattered fine buckets %u", sb, c->sk_kfbits);
         LAUNCH_LDS(c, "k_sk_dedup", k_sk_dedup, P3_NB << sb, nwaves * 64, lds_sk, (const uint4*)c->kpart.p,
-                   (const u32*)c->ghist.p, c->sk_ksegcap, sb, ts_log2, k, (u64*)c->dkeys.p, dst);
+                   (const u32*)c->ghist.p, c->sk_ksegcap, c->sk_kfbits, sb - c->sk_kfbits, ts_log2, k, (u64*)c->dkeys.p, dst);
         return P3_OK;
       }
       if (!xg) {
@@ -1454,8 +1477,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       if ((rc = dedup_once(sbits, kxg))) return rc;
     } else {
       while (sbits < 5 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (64u << ts_log2)) sbits++;
-      if (c->kpart_sk)  // 8 Ki-slot sets: <= 8 instances per slot to start with
+      if (c->kpart_sk) {  // 8 Ki-slot sets: <= 8 instances per slot to start with, never coarser than the fine buckets
         for (sbits = 0; sbits < 6 && (c->n_words * 32) / ((u64)P3_NB << sbits) > (8ull << ts_log2); sbits++) {}
+        if (sbits < c->sk_kfbits) sbits = c->sk_kfbits;
+      }
       // the split that worked for the previous pass over the same reads and k is the best first guess
       if (c->ksbits_epoch == c->reads_epoch && c->ksbits_k == k) {
         if (c->kxg) {
@@ -2002,6 +2027,11 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "run_records") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "run_records must be 0 (auto), 1 (never) or 2 (wherever they apply)");
     c->sk_opt = (int)value;
+  } else if (n == "sk_waves") {
+    if (value < 4 || value > 16) return fail(c, P3_EBADARG, "sk_waves must be in [4,16]");
+    c->sk_waves_opt = (int)value;
+  } else if (n == "sk_dbg") {
+    c->sk_dbg = (int)value;
   } else if (n == "sk_ts_log2") {
     if (value < 6 || value > 13) return fail(c, P3_EBADARG, "sk_ts_log2 must be in [6,13]");
     c->sk_ts_log2_opt = (int)value;
