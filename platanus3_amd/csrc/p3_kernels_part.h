@@ -26,6 +26,7 @@
 #define P3_NWG 256u             // workgroups of the hist/scatter kernels (static word partition)
 #define P3_K2_WEIGHTED 1u       // k_part_count mode bits (multi-rank pre-aggregation)
 #define P3_K2_AGG_OUT 2u
+#define P3_K2_SUMCHECK 4u       // add up the instances a table takes in: a u32 counter cannot wrap below 2^32 of them
 #define P3_PART_THREADS 1024
 #define P3_TS_LOG2_MAX 14       // LDS count table: 16384 slots x (4 B remainder + 4 B count) = 128 KiB
 #define P3_EMPTY32 0xffffffffu
@@ -316,6 +317,11 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   // (bits 62..32) times at the sender", clear = one instance at window position (bits 62..32).
   // mode & P3_K2_AGG_OUT (POS only): emit such records instead of the table (the sender side of the above).
   const bool weighted = POS && (mode & P3_K2_WEIGHTED);
+  // gstats[29] is raised when this table took in 2^32 instances or more (weights included): only then could one of its
+  // u32 counters have wrapped, which the max_count >= 2^31 test of the host (the reference's RMQ truncates through
+  // int, src/MakeBloomFilter.cpp:11,18) would not see.  Asked for by the host when that many instances exist at all.
+  const bool sumcheck = POS && (mode & P3_K2_SUMCHECK);
+  u64 wsum = 0;
   auto weight_of = [&](REC item) -> u32 {
     if constexpr (POS) {
       if (weighted && ((u64)item >> 63)) return (u32)((u64)item >> 32) & 0x7fffffffu;
@@ -350,6 +356,8 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
     s_nsolid = 0;
     s_max = 0;
     s_ovf = 0;
+    sc[10] = 0;
+    sc[11] = 0;
   }
   if (threadIdx.x < 128) sc[16 + threadIdx.x] = 0;
   __syncthreads();
@@ -430,6 +438,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       for (int t = 0; t < G; t++) {
         const int i = g0 + t;
         const bool mine = (act & (1u << i)) && ((((u32)r[i] >> rem_bits) & sub_mask) == subsel);
+        if (sumcheck && mine) wsum += weight_of(r[i]);
         const bool hit = mine && cur[t] == rem[t];
         if (hit) atomicAdd(&tcnt[slot[t]], weight_of(r[i]));
         const bool miss = mine && !hit;
@@ -473,8 +482,13 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
       qn = 0;
     }
   }
+  if (sumcheck) {
+    for (int off = 32; off > 0; off >>= 1) wsum += __shfl_down(wsum, off, 64);
+    if (lane == 0 && wsum) atomicAdd((unsigned long long*)(sc + 10), (unsigned long long)wsum);  // sc[10..11]: u64, zeroed above
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (sumcheck && (((u64)sc[11] << 32) | sc[10]) >= (1ULL << 32)) gstats[29] = 1;
     if (s_ovf) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
     const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)s_ndist);
     s_base_lo = (u32)base;

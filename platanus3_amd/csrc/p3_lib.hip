@@ -476,7 +476,7 @@ int do_count_direct(p3_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[2];
+  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[3];
   c->count_mode = 1;
   c->gate_mode = 1;
@@ -694,6 +694,12 @@ int var_caps_prepare(p3_ctx* c) {
 
 // the count kernel's two rarely used inputs (see k_part_count): dstats[30] = entries its table outputs hold,
 // sing_cursor[P3_MAX_RANKS + s] = start of source s's list in `singles` (copied from the device table `sroff`, n of them)
+// k_part_count mode bits: weighted records; and the instance sum check wherever a u32 counter could wrap at all
+u32 k2_mode(const p3_ctx* c) {
+  const u64 instances = c->n_words_all ? c->n_words_all * 32 : c->n_words * 32;
+  return (c->rx_weighted ? (P3_K2_WEIGHTED | P3_K2_SUMCHECK) : 0u) | (instances >= (1ull << 32) ? P3_K2_SUMCHECK : 0u);
+}
+
 int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
   int rc;
   if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
@@ -749,6 +755,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if ((rc = set_k2ext(c, maxd, c->n_ranks > 1 ? c->rx_roff.p : nullptr, c->n_ranks))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 29, 0, 8, c->stream));
   const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
   if (c->part_sk) {
     if (sbits < c->sk_fbits) return fail(c, P3_EHIP, "run records: split %u below the scattered fine buckets %u", sbits, c->sk_fbits);
@@ -773,13 +780,13 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
-                 (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+                 k2_mode(c));
     } else {
       LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
-                 (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+                 k2_mode(c));
     }
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
@@ -818,7 +825,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[2];
+  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];  // this rank's windows (local partition)
   c->ccounts_u32 = true;
   return P3_OK;
@@ -851,6 +858,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 29, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 31, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
@@ -892,12 +900,12 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
       LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
     } else {
       LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, (u32)(c->rx_weighted ? P3_K2_WEIGHTED : 0u));
+                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
     }
   }
   HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
@@ -924,7 +932,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[2];
+  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];
   return P3_OK;
 }
@@ -1663,7 +1671,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (hall[3] || hall[16 + 3]) return fail(c, P3_ERETRY_INTERNAL, "an LDS table overflowed under the previous split");
     c->cstats.n_distinct = hall[0];
     c->cstats.n_solid = hall[1];
-    c->cstats.max_count = hall[2];
+    c->cstats.max_count = hall[29] ? std::max<u64>(hall[2], 1ull << 32) : hall[2];
     c->cstats.n_windows = hall[5];
     c->n_distinct_k = hall[16];
     if (c->cstats.max_count >= (1ULL << 31))

@@ -909,3 +909,63 @@ def test_random_configurations_medium(oracle, seed):
         raise AssertionError("%s: %s: %s" % (what, type(e).__name__, e))
     finally:
         c.close()
+
+
+def test_count_overflow_is_reported_not_truncated(oracle):
+    """G1 guard: the reference's RMQ passes the 21-mer counts through an int (src/MakeBloomFilter.cpp:11,18), so a count
+    >= 2^31 would be truncated there; the ABI reports P3_ECOUNT_OVERFLOW instead of diverging silently.  Reached cheaply
+    through the multi-rank protocol's pre-aggregated records (weight = the sender's local count): two records of one key
+    are patched to weight 2^31 - 1 each on their way to the owner."""
+    import threading
+    import torch
+    from loopback_comm import LoopbackWorld, LoopbackComm
+    from platanus3_amd.pipeline import Pipeline
+    world, k, n_reads = 2, 31, 8000
+    per = n_reads // world
+    b, o = synth.reads(seed=43, total_reads=n_reads, read_len=150)
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    lw = LoopbackWorld(world)
+
+    class PatchComm(LoopbackComm):
+        """rank 0's comm: after the record blob and its two descriptor tables have arrived, raise two weights"""
+        def __init__(self, w, rank):
+            super().__init__(w, rank)
+            self.seen = []
+
+        def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+            super().all_to_all_single(out, inp, out_splits, in_splits)
+            self.seen.append(out)
+            if len(self.seen) == 4:  # counts, records, ghist, segoff
+                part, ghist, segoff = self.seen[1], self.seen[2], self.seen[3]
+                g = ghist.cpu().numpy()
+                so = segoff.cpu().numpy()
+                s = int(np.nonzero(g[: g.size // world] >= 2)[0][0])  # a segment of source 0 with two records
+                idx = int(so[s]) - int(so[0])
+                v = part[idx:idx + 2].cpu().numpy().view(np.uint64)
+                low = v[0] & np.uint64(0xffffffff)
+                heavy = (np.uint64(1) << np.uint64(63)) | (np.uint64(0x7fffffff) << np.uint64(32)) | low
+                part[idx:idx + 2] = torch.from_numpy(np.array([heavy, heavy], np.uint64).view(np.int64)).to(part.device)
+                torch.cuda.synchronize()
+
+    errors = [None] * world
+
+    def worker(r):
+        try:
+            bb = b[int(o[r * per]):int(o[(r + 1) * per])]
+            oo = o[r * per:(r + 1) * per + 1] - o[r * per]
+            comm = PatchComm(lw, r) if r == 0 else lw.comm(r)
+            pipe = Pipeline(device=0, rank=r, world=world, comm=comm)
+            pipe.ctx.set_option("mr_aggregate", 2)
+            pipe.load_reads(bb, oo, min_len=k)
+            pipe.run_pass(k, m, H)
+        except Exception as e:  # noqa: BLE001
+            errors[r] = e
+            lw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    e0 = errors[0]
+    assert isinstance(e0, capi.P3Error) and e0.code == 6, errors  # P3_ECOUNT_OVERFLOW
