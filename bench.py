@@ -4,10 +4,22 @@
   python bench.py --gpus 1 --steps K --warmup W                                  (single MI355X)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...    (one rank per GPU)
 
-A "step" is one whole pass (reference CountShortKmer + MakeBF, src/Assemble.cpp:9-12) over one batch
-of synthetic reads that is already resident in HBM as 1 B/base ASCII + offsets.  Workload at N=1 =
-BASELINE config #2 (1 M x 150 bp, k=31, Bloom sizing from Options::EstimateBloomfilter).  For N>1 the
-per-GPU batch is fixed (weak scaling): N x 1 M reads drawn from one common genome, sharded by read index.
+A "step" is one whole pass (reference CountShortKmer + MakeBF, src/Assemble.cpp:9-12) over one batch of synthetic
+reads that is already resident in HBM as 1 B/base ASCII + offsets.
+
+Workloads (--config, BASELINE.json `configs`):
+  2  (default at N=1)  1 M x 150 bp, k=31, one GPU: the headline line (metric quoted on this config)
+  3  (default at N>1)  50 M x 150 bp TOTAL, k=31, sharded by read index over the N ranks: STRONG scaling.  The N=1 run
+                       of the same 50 M reads is what a ratio is taken against; the default N=1 run measures it too and
+                       reports it as `scale_base`
+  5                    10 M x 150 bp total, k = 21, 31, 41, 51, 61: five independent passes (the reference has no
+                       iterative-k loop), value = all their k-mers / all their time, per-k list in `config.per_k`
+Bloom sizing = Options::EstimateBloomfilter of the reference for that input.
+
+What a timed step reuses: the steps run over the SAME resident reads, so after the warm-up passes the library replays the
+pass with what it learnt (sub-bucket splits, segment capacities, buffer sizes) and synchronises once per pass ("warm").
+A job that sees each input once pays the careful first pass instead: `cold` in the JSON line = the same pass with
+those hints dropped before every step (buffers stay allocated), timed separately.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for the roofline and cpu_baseline objects).
 """
@@ -21,6 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+CONFIG3_READS = 50_000_000
+CONFIG5_READS = 10_000_000
+CONFIG5_K = (21, 31, 41, 51, 61)
 
 
 def parse():
@@ -28,12 +43,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="reads PER GPU")
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 5), help="0 = 2 at one GPU, 3 at several")
+    ap.add_argument("--reads", type=int, default=0, help="override the TOTAL number of reads of the chosen config")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
+    ap.add_argument("--seed", type=int, default=0, help="0 = the config index")
+    ap.add_argument("--cold-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000, help="reads of the CPU baseline (config #2 in full)")
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock guard of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-base", action="store_true", help="skip the N=1 measurement of config #3")
     ap.add_argument("--force-protocol", action="store_true",
                     help="run the multi-rank protocol code path even with one rank (testing)")
     return ap.parse_args()
@@ -49,27 +68,39 @@ def bloom_sizing(all_bases, k):
     return m, H
 
 
-def cpu_baseline(args, k):
-    """The reference CPU path (or its reference-shaped port) on a bounded sample, 1 core."""
+def cpu_baseline(args, k, seed):
+    """The reference CPU path (or its reference-shaped port) on the GPU box's host, ONE core (both stages are serial in
+    the reference, src/Load.cpp:105-127, src/MakeBloomFilter.cpp:43-86).  Config #2 in full when a short calibration
+    run predicts it fits the wall-clock guard; otherwise the largest prefix that does, labelled "subsampled"."""
     import platanus3_amd.synth as synth
     from oracle.p3_oracle import Oracle, RefLib
-    n = args.cpu_sample_reads
-    b, o = synth.reads(seed=args.seed, total_reads=n, read_len=args.read_len)
-    m, H = bloom_sizing(int(b.size), k)
-    n_k = n * (args.read_len - k + 1)
-    if os.path.exists(RefLib.PATH):
-        ref = RefLib()
-        out = ref.run((b, o), k, m, H)
-        t = out["t_count"] + out["t_bloom"]
-        kind = "reference"
-    else:
-        out = Oracle().refshaped_pass((b, o), k, m, H)
-        t = out["t_count"] + out["t_bloom"]
-        kind = "port"
-    return {"value": n_k / t, "unit": "k-mers/s", "cores": 1, "kind": kind,
+    L = args.read_len
+    use_ref = os.path.exists(RefLib.PATH)
+
+    def run(n):
+        b, o = synth.reads(seed=seed, total_reads=n, read_len=L)
+        m, H = bloom_sizing(int(b.size), k)
+        out = RefLib().run((b, o), k, m, H) if use_ref else Oracle().refshaped_pass((b, o), k, m, H)
+        return out, m, H
+
+    want = args.cpu_sample_reads
+    n_cal = min(want, 60_000)
+    out, m, H = run(n_cal)
+    t_cal = out["t_count"] + out["t_bloom"]
+    n = want
+    if n > n_cal:
+        # the per-read cost grows with the table (cache misses of the unordered_map): x3.5 from 60 k to 1 M reads measured
+        predicted = t_cal * (want / n_cal) * 3.5
+        if predicted > args.cpu_budget_s:
+            n = max(n_cal, int(want * args.cpu_budget_s / predicted))
+        out, m, H = run(n)
+    t = out["t_count"] + out["t_bloom"]
+    n_k = n * (L - k + 1)
+    label = "config #2 in full: " if n == 1_000_000 and L == 150 else ("subsampled: " if n < want else "")
+    return {"value": n_k / t, "unit": "k-mers/s", "cores": 1, "kind": "reference" if use_ref else "port",
             "host_cores": os.cpu_count(),
-            "sample": "%d x %d bp synthetic reads (same generator, 30x coverage), k=%d, m=%d, H=%d; "
-                      "CountShortKmer %.2f s + MakeBF %.2f s single-threaded" % (n, args.read_len, k, m, H,
+            "sample": "%s%d x %d bp synthetic reads (same generator, 30x coverage), k=%d, m=%d, H=%d; "
+                      "CountShortKmer %.2f s + MakeBF %.2f s single-threaded" % (label, n, L, k, m, H,
                                                                               out["t_count"], out["t_bloom"])}
 
 
@@ -87,105 +118,182 @@ def main():
     import torch
     import torch.distributed as dist
     import platanus3_amd.synth as synth
-    from platanus3_amd import capi
-    from platanus3_amd.pipeline import Pipeline
+    from platanus3_amd.pipeline import Pipeline, VirtualRanks
 
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    k, L = args.k, args.read_len
-    total_reads = args.reads * world
-    b, o = synth.reads(seed=args.seed, total_reads=total_reads, first_read=rank * args.reads, n_reads=args.reads,
-                       read_len=L)
+    config = args.config or (2 if world == 1 else 3)
+    L = args.read_len
+    total_reads = args.reads or {2: 1_000_000, 3: CONFIG3_READS, 5: CONFIG5_READS}[config]
+    seed = args.seed or config
+    ks = CONFIG5_K if config == 5 else (args.k,)
+    per = total_reads // world
+    total_reads = per * world
     all_bases = total_reads * L
-    m, H = bloom_sizing(all_bases, k)
-    n_k_total = total_reads * (L - k + 1)
-
-    pipe = Pipeline(device=local_rank, rank=rank, world=world, force_protocol=args.force_protocol)
-    pipe.load_reads(b, o, min_len=k)  # H2D, untimed: inputs are resident in HBM when the clock starts
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        pipe.synchronize()
 
-    for _ in range(args.warmup):
-        pipe.run_pass(k, m, H)
-    # One extra untimed pass with HIP events around EVERY launch: per-kernel split + which kernel dominates.
-    # (A bracket costs ~10 us of stream time, ~0.45 ms per pass if all ~45 launches carried one, so the timed
-    # steps below bracket only the dominant kernel.)
-    pipe.ctx.reset_kernel_stats()
-    pipe.ctx.set_profiling(True)
-    pipe.run_pass(k, m, H)
-    pipe.ctx.set_profiling(False)
-    split = pipe.ctx.kernel_stats()
-    dom_name = max(split.items(), key=lambda kv: kv[1]["total_ms"])[0] if split else None
-    if world > 1:  # every rank must bracket the same kernel (identical programs; agree on rank 0's choice anyway)
-        obj = [dom_name]
-        dist.broadcast_object_list(obj, src=0)
-        dom_name = obj[0]
-    pipe.ctx.reset_kernel_stats()
-    pipe.ctx.set_profiling(True, only=dom_name)  # live HIP-event timing of the dominant kernel in the timed region
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.run_pass(k, m, H)
-    barrier()
-    dt = time.perf_counter() - t0
-    pipe.ctx.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def make_pipe(n_total, n_mine, first, seed=seed):
+        """the rank's shard resident in HBM.  A shard beyond what one protocol rank takes (2^30 window positions) is
+        hosted as several VIRTUAL ranks on this GPU (pipeline.VirtualRanks); one GPU alone uses the library's own
+        position chunks."""
+        if world == 1 and not args.force_protocol:
+            b, o = synth.reads(seed=seed, total_reads=n_total, first_read=first, n_reads=n_mine, read_len=L)
+            p = Pipeline(device=local_rank, rank=0, world=1)
+            p.load_reads(b, o, min_len=max(ks))
+            return p
+        v = 1
+        while (n_mine // v) * L > (1 << 30) - (1 << 24):
+            v *= 2
+        if v == 1:
+            b, o = synth.reads(seed=seed, total_reads=n_total, first_read=first, n_reads=n_mine, read_len=L)
+            p = Pipeline(device=local_rank, rank=rank, world=world, force_protocol=args.force_protocol)
+            p.load_reads(b, o, min_len=max(ks))
+            return p
+        return VirtualRanks(device=local_rank, rank=rank, world=world, per_rank=v, seed=seed, total_reads=n_total,
+                            first_read=first, n_reads=n_mine, read_len=L, min_len=max(ks))
 
-    ms_per_step = dt * 1000.0 / args.steps
-    value = n_k_total / (dt / args.steps)
+    def timed(pipe, k, m, H, steps, cold=False):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if cold:
+                pipe.drop_hints()
+            pipe.run_pass(k, m, H)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    pipe = make_pipe(total_reads, per, rank * per)  # H2D untimed: inputs are resident in HBM when the clock starts
+    per_k = []
+    stats0 = {}
+    roof = None
+    split = {}
+    dom_name = None
+    cold = None
+    dt_all, nk_all = 0.0, 0
+    for k in ks:
+        m, H = bloom_sizing(all_bases, k)
+        n_k_total = total_reads * (L - k + 1)
+        for _ in range(args.warmup):
+            pipe.run_pass(k, m, H)
+        ctx = pipe.ctx
+        if k == ks[0] and ctx is not None:
+            # One extra untimed pass with HIP events around EVERY launch: per-kernel split + which kernel dominates.  (A
+            # bracket costs ~10 us of stream time, so the timed steps below bracket only the dominant kernel.)
+            ctx.reset_kernel_stats()
+            ctx.set_profiling(True)
+            pipe.run_pass(k, m, H)
+            ctx.set_profiling(False)
+            split = ctx.kernel_stats()
+            dom_name = max(split.items(), key=lambda kv: kv[1]["total_ms"])[0] if split else None
+            if world > 1:  # every rank must bracket the same kernel (identical programs; agree on rank 0's choice anyway)
+                obj = [dom_name]
+                dist.broadcast_object_list(obj, src=0)
+                dom_name = obj[0]
+            ctx.reset_kernel_stats()
+            ctx.set_profiling(True, only=dom_name)  # live HIP-event timing of the dominant kernel in the timed region
+        dt = timed(pipe, k, m, H, args.steps)
+        if ctx is not None:
+            ctx.set_profiling(False)
+            if k == ks[0]:
+                stats0 = ctx.kernel_stats()
+        per_k.append({"k": k, "m": m, "H": H, "ms_per_step": dt * 1000.0 / args.steps, "value": n_k_total / (dt / args.steps)})
+        dt_all += dt
+        nk_all += n_k_total
+        if k == ks[-1] and args.cold_steps > 0:
+            dtc = timed(pipe, k, m, H, args.cold_steps, cold=True)
+            cold = {"ms_per_step": dtc * 1000.0 / args.cold_steps, "value": n_k_total / (dtc / args.cold_steps),
+                    "steps": args.cold_steps,
+                    "what": "hints of earlier passes dropped before every step (first pass over new reads; buffers kept)"}
+
+    ms_per_step = dt_all * 1000.0 / args.steps
+    value = nk_all / (dt_all / args.steps)
     D = pipe.global_distinct()  # collective: every rank takes part
+    cst = pipe.count_stats()
+    passing = pipe.passing_kmers()
+    pipe_parallelism = pipe.parallelism()
+    stats = stats0
+
+    scale_base = None
+    if config == 2 and world == 1 and not args.no_scale_base and not args.reads:
+        # the N=1 point of the strong-scaling curve (config #3: the same 50 M reads the N>1 runs shard), measured here
+        # so that the default single-GPU run carries it
+        pipe.close()
+        pipe = None
+        m3, H3 = bloom_sizing(CONFIG3_READS * L, 31)
+        p3 = make_pipe(CONFIG3_READS, CONFIG3_READS, 0, seed=3)
+        p3.run_pass(31, m3, H3)
+        s3 = 3
+        t0 = time.perf_counter()
+        for _ in range(s3):
+            p3.run_pass(31, m3, H3)
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t0) / s3
+        scale_base = {"workload": "%d x %d bp synthetic reads on ONE GPU (config #3, 30x, 0.5%% subst), k=31, m=%d, H=%d"
+                                  % (CONFIG3_READS, L, m3, H3),
+                      "ms_per_step": dt3 * 1000.0, "value": CONFIG3_READS * (L - 31 + 1) / dt3, "unit": "k-mers/s", "steps": s3}
+        p3.close()
+
     if rank == 0:
-        stats = pipe.ctx.kernel_stats()
-        cst = pipe.ctx.count_stats()
         R = total_reads
+        k0 = ks[0]
+        m0 = per_k[0]["m"]
         # ALGORITHMIC bytes (SURVEY.md section 8d): B_alg(read) = 2L + 16(L-20) + 16 D/R + m/(8R)
-        b_alg_read = 2 * L + 16 * (L - 20) + 16.0 * D / R + m / (8.0 * R)
-        b_alg_kmer = b_alg_read / (L - k + 1)
-        # split by stage so a kernel is only credited with the bytes of the stage it implements
-        stage_bytes = pipe.stage_alg_bytes(L, D, R, m)
-        dom = stats.get(dom_name)
-        roof = None
-        if dom:
+        b_alg_read = 2 * L + 16 * (L - 20) + 16.0 * D / R + m0 / (8.0 * R)
+        b_alg_kmer = b_alg_read / (L - k0 + 1)
+        stage_bytes = Pipeline.stage_alg_bytes(L, D, R, m0)
+        dom = stats.get(dom_name) if dom_name else None
+        if dom and dom["launches"]:
             avg_ms = dom["total_ms"] / dom["launches"]
-            per_launch_bytes = stage_bytes.get(dom_name, 0.0) * (args.reads)  # this rank's reads per launch
+            per_launch_bytes = stage_bytes.get(dom_name, 0.0) * per  # this rank's reads per launch
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/), if this kernel is in them
-            try:
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")) as f:
-                    traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
-            except (OSError, ValueError, KeyError):
-                pass
+            if config == 2:
+                try:
+                    with open(os.path.join(ROOT, "profiles", "pmc_traffic_current.json")) as f:
+                        traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+                except (OSError, ValueError, KeyError):
+                    pass
+            v1 = per_k[0]["value"]
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_ms,
-                    "alg_bytes_per_launch": per_launch_bytes,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_note": "PMC estimate (FETCH_SIZE x2 for wide streaming reads applied per kernel by hand)",
+                    "avg_launch_ms": avg_ms, "alg_bytes_per_launch": per_launch_bytes,
                     "pass_alg_bytes_per_kmer": b_alg_kmer,
-                    "pass_frac": (value / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
+                    "pass_frac": (v1 / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
                     # SURVEY.md section 8d asks for both peaks: against the 6.29 TB/s a device copy reaches
                     "frac_of_achievable_6290": achieved / 6290.0,
-                    "pass_frac_of_achievable_6290": (value / world) * b_alg_kmer / 6.29e12,
+                    "pass_frac_of_achievable_6290": (v1 / world) * b_alg_kmer / 6.29e12,
                     "kernels_ms_per_step": {n: s["total_ms"] for n, s in sorted(split.items())}}
-        out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d; 1/2/4/8 MI355X + %%HBM roofline" % k, "value": value, "unit": "k-mers/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-               "config": {"workload": "%d x %d bp synthetic reads per GPU (%d total, 30x, 0.5%% subst), k=%d, "
-                                      "Bloom m=%d bits H=%d (EstimateBloomfilter), count+gate+Bloom+seeds"
-                                      % (args.reads, L, total_reads, k, m, H),
-                          "parallelism": "reads sharded by index x%d" % world,
-                          "distinct_21mers": D, "solid_21mers": cst["n_solid"],
-                          "passing_kmers": pipe.ctx.bloom_stats()["n_passing"]},
-               "roofline": roof}
+        names = {2: "config #2", 3: "config #3", 5: "config #5"}
+        wl = "%s: %d x %d bp synthetic reads in total (%d per GPU, 30x, 0.5%% subst), k=%s, Bloom m=%s bits H=%d " \
+             "(EstimateBloomfilter), count+gate+Bloom+seeds" % (names[config], total_reads, L, per, "/".join(str(x) for x in ks),
+                                                                "/".join(str(x["m"]) for x in per_k), per_k[0]["H"])
+        out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d; 1/2/4/8 MI355X + %%HBM roofline" % args.k, "value": value,
+               "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64",
+               "data": "synthetic",
+               "config": {"workload": wl, "parallelism": pipe_parallelism, "distinct_21mers": D, "solid_21mers": cst["n_solid"],
+                          "passing_kmers": passing,
+                          "timed_step": "warm: the steps replay the pass over the same resident reads with the splits and "
+                                        "sizes learnt in the warm-up passes, one synchronisation per pass; see `cold`"},
+               "roofline": roof, "cold": cold}
+        if config == 5:
+            out["config"]["per_k"] = per_k
+        if scale_base:
+            out["scale_base"] = scale_base
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, k)
+            out["cpu_baseline"] = cpu_baseline(args, 31 if config == 5 else ks[0], 2)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

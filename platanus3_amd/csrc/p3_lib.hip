@@ -2032,6 +2032,20 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "mr_aggregate") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
     c->agg_opt = (int)value;
+  } else if (n == "drop_hints") {
+    // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
+    // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
+    c->hint_valid = false;
+    c->ksbits_epoch = ~0ull;
+    c->sbits_epoch = ~0ull;
+    c->pass_hint = 0;
+    c->kxg = 0;
+    c->est_boost = 0;
+    c->est_ok = true;
+    c->chunk_ok = true;
+    c->kcollect_ok = true;
+    c->sk_ok = true;
+    c->sk_boost = 0;
   } else if (n == "run_records") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "run_records must be 0 (auto), 1 (never) or 2 (wherever they apply)");
     c->sk_opt = (int)value;

@@ -271,6 +271,22 @@ class Pipeline:
     def global_distinct(self):
         return self.comm.all_reduce_sum(self.ctx.count_stats()["n_distinct"])
 
+    def count_stats(self):
+        return self.ctx.count_stats()
+
+    def passing_kmers(self):
+        return self.comm.all_reduce_sum(self.ctx.bloom_stats()["n_passing"])
+
+    def drop_hints(self):
+        """forget what earlier passes over these reads learnt: the next pass is a FIRST pass (bench.py `cold`)"""
+        self.ctx.set_option("drop_hints", 1)
+
+    def parallelism(self):
+        return "reads sharded by index x%d" % self.world
+
+    def close(self):
+        self.ctx.close()
+
     @staticmethod
     def stage_alg_bytes(L, D, R, m):
         """Per-read ALGORITHMIC bytes credited to each kernel; they sum to SURVEY.md section 8d's
@@ -288,3 +304,205 @@ class Pipeline:
             "k_bloom_slices": m / (8.0 * R), "k_bloom_insert": m / (8.0 * R),
         }
         return {kname: own.get(kname, 0.0) for kname in STAGE_OF}
+
+
+
+# ---- several protocol ranks per GPU -----------------------------------------------------------------------------------
+# One rank of the multi-rank protocol takes at most 2^30 window positions (its partition records address a window by a
+# 30-bit position).  BASELINE config #3 (50 M x 150 bp) sharded over 2 or 4 GPUs exceeds that per GPU, so a GPU then hosts
+# several VIRTUAL ranks: `per_rank` contexts, each with its own slice of the GPU's shard, driven by threads.  The protocol
+# runs unchanged over V = world x per_rank ranks; collectives between virtual ranks are copies inside one process and
+# torch.distributed (RCCL) between processes.  Virtual rank ids are process-major: process p hosts p * per_rank ... .
+
+class _HybridWorld:
+    def __init__(self, per_rank, rank, world, group=None):
+        import threading
+        self.v, self.rank, self.world, self.group = per_rank, rank, world, group
+        self.barrier = threading.Barrier(per_rank)
+        self.slot = [None] * per_rank
+        self.result = None
+
+    def comm(self, i):
+        return HybridComm(self, i)
+
+
+class HybridComm:
+    """collectives among V = world x v virtual ranks; the local leader (thread 0) talks to the other processes"""
+
+    def __init__(self, w, i):
+        self.w, self.i = w, i
+        self.rank, self.world = w.rank * w.v + i, w.world * w.v
+
+    def _sync(self, t):
+        if getattr(t, "is_cuda", False):
+            import torch
+            torch.cuda.synchronize()
+
+    def _dist(self):
+        import torch.distributed as dist
+        return dist
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+        import torch
+        w, v, W, V = self.w, self.w.v, self.w.world, self.world
+        self._sync(inp)
+        w.slot[self.i] = (out, inp, out_splits, in_splits)
+        w.barrier.wait()
+        if self.i == 0:
+            items = list(w.slot)
+
+            def in_block(s, dv):   # what local source s sends to virtual rank dv
+                _, sinp, _, ssp = items[s]
+                if ssp is None:
+                    ln = sinp.numel() // V
+                    return sinp[dv * ln:(dv + 1) * ln]
+                off = sum(ssp[:dv])
+                return sinp[off:off + ssp[dv]]
+
+            def out_len(d, sv):    # what local destination d receives from virtual rank sv
+                dout, _, dsp, _ = items[d]
+                return dout.numel() // V if dsp is None else dsp[sv]
+
+            send_blocks, send_sizes = [], []
+            for p in range(W):     # to process p: [local source s][its destination d]
+                n = 0
+                for s in range(v):
+                    for d in range(v):
+                        blk = in_block(s, p * v + d)
+                        send_blocks.append(blk)
+                        n += blk.numel()
+                send_sizes.append(n)
+            send = torch.cat(send_blocks) if send_blocks else inp[:0]
+            recv_sizes = [sum(out_len(d, q * v + s) for s in range(v) for d in range(v)) for q in range(W)]
+            if W > 1:
+                recv = torch.empty(sum(recv_sizes), dtype=send.dtype, device=send.device)
+                self._dist().all_to_all_single(recv, send, output_split_sizes=recv_sizes, input_split_sizes=send_sizes,
+                                               group=w.group)
+            else:
+                recv = send
+            pos = 0
+            for q in range(W):     # from process q: [its source s][local destination d]
+                for s in range(v):
+                    for d in range(v):
+                        dout, _, dsp, _ = items[d]
+                        sv = q * v + s
+                        ln = out_len(d, sv)
+                        off = sv * ln if dsp is None else sum(dsp[:sv])
+                        dout[off:off + ln].copy_(recv[pos:pos + ln])
+                        pos += ln
+            self._sync(send)
+        w.barrier.wait()
+
+    def all_gather_into_tensor(self, out, inp):
+        import torch
+        w, v, W = self.w, self.w.v, self.w.world
+        self._sync(inp)
+        w.slot[self.i] = (out, inp)
+        w.barrier.wait()
+        if self.i == 0:
+            items = list(w.slot)
+            send = torch.cat([it[1] for it in items])
+            if W > 1:
+                big = torch.empty(send.numel() * W, dtype=send.dtype, device=send.device)
+                self._dist().all_gather_into_tensor(big, send, group=w.group)
+            else:
+                big = send
+            for it in items:
+                it[0].copy_(big)
+            self._sync(send)
+        w.barrier.wait()
+
+    def _reduce(self, val, op_name):
+        import torch
+        w = self.w
+        w.slot[self.i] = int(val)
+        w.barrier.wait()
+        if self.i == 0:
+            r = max(w.slot) if op_name == "max" else sum(w.slot)
+            if w.world > 1:
+                dist = self._dist()
+                dev = "cuda" if dist.get_backend(w.group) == "nccl" else "cpu"
+                t = torch.tensor([r], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if op_name == "max" else dist.ReduceOp.SUM, group=w.group)
+                r = int(t.item())
+            w.result = r
+        w.barrier.wait()
+        r = w.result
+        w.barrier.wait()
+        return r
+
+    def all_reduce_max(self, val):
+        return self._reduce(val, "max")
+
+    def all_reduce_sum(self, val):
+        return self._reduce(val, "sum")
+
+
+class VirtualRanks:
+    """`per_rank` protocol ranks on one GPU (one process of `world`), same surface as Pipeline for bench.py.
+    backends: optional list of per-virtual-rank backends (the CPU tests pass their stand-in); reads: optional list of
+    (bases, offsets) per virtual rank -- otherwise every virtual rank generates its slice of the synthetic set."""
+
+    def __init__(self, device=0, rank=0, world=1, per_rank=2, seed=1, total_reads=0, first_read=0, n_reads=0, read_len=150,
+                 min_len=21, group=None, backends=None, reads=None):
+        from . import synth
+        self.rank, self.world, self.v = rank, world, per_rank
+        self.hw = _HybridWorld(per_rank, rank, world, group)
+        self.pipes = []
+        per = n_reads // per_rank
+        for i in range(per_rank):
+            be = backends[i] if backends is not None else None
+            pipe = Pipeline(device=device, rank=rank * per_rank + i, world=world * per_rank, backend=be, comm=self.hw.comm(i))
+            if reads is not None:
+                b, o = reads[i]
+            else:
+                b, o = synth.reads(seed=seed, total_reads=total_reads, first_read=first_read + i * per, n_reads=per,
+                                   read_len=read_len)
+            pipe.load_reads(b, o, min_len=min_len)
+            self.pipes.append(pipe)
+        self.ctx = None  # (no single context: per-kernel statistics are not collected in this form)
+
+    def _each(self, fn):
+        import threading
+        out, errs = [None] * self.v, []
+
+        def work(i):
+            try:
+                out[i] = fn(self.pipes[i])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+                self.hw.barrier.abort()
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(self.v)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            self.hw.barrier.reset()
+            raise errs[0]
+        return out
+
+    def run_pass(self, k, m, H):
+        self._each(lambda p: p.run_pass(k, m, H))
+
+    def drop_hints(self):
+        for p in self.pipes:
+            p.drop_hints()
+
+    def global_distinct(self):
+        return self._each(lambda p: p.global_distinct())[0]
+
+    def passing_kmers(self):
+        return self._each(lambda p: p.passing_kmers())[0]
+
+    def count_stats(self):
+        return {"n_solid": self._each(lambda p: p.comm.all_reduce_sum(p.ctx.count_stats()["n_solid"]))[0]}
+
+    def parallelism(self):
+        return "reads sharded by index x%d (%d protocol ranks per GPU)" % (self.world, self.v)
+
+    def close(self):
+        for p in self.pipes:
+            if p.ctx is not None:
+                p.ctx.close()
