@@ -168,6 +168,10 @@ int p3_get_graph_stats(p3_ctx* ctx, p3_graph_stats* out);
 int p3_export_junctions(p3_ctx* ctx, uint64_t* keys, int32_t* coverage, int32_t* left_cov, int32_t* right_cov,
                         uint64_t cap, uint64_t* n);
 int p3_export_straights(p3_ctx* ctx, uint64_t* seq_off, char* seq, uint64_t cap_n, uint64_t cap_bases, uint64_t* n);
+/* JointInfo::coverage (src/DeBruijnGraph.cpp:24-28, filled by AddNodeCoverage :441-449; never printed by the
+ * reference): two entries per straight in p3_export_straights order, [2i] = the joint that starts straight i's sequence
+ * (its first k-mer), [2i+1] = the one that ends it. */
+int p3_export_joints(p3_ctx* ctx, int32_t* coverage, uint64_t cap, uint64_t* n);
 int p3_export_edges(p3_ctx* ctx, uint32_t* a, uint32_t* b, uint64_t cap, uint64_t* n);
 /* PrintGraph (src/DeBruijnGraph.cpp:451-544): GFA 1.0 text in the reference's format */
 int p3_write_gfa(p3_ctx* ctx, const char* path);

@@ -76,6 +76,9 @@ class Oracle:
         L.p3o_dbg.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, C.c_int, _u64p, C.c_uint64, C.c_int, _u64p, C.c_uint64,
                               C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.p3o_dbg_joints.argtypes = [_u8p, _u64p, C.c_uint64, C.c_uint32, C.c_int, _u64p, C.c_uint64, C.c_int, _u64p, C.c_uint64,
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_uint64)]
         L.p3o_free.argtypes = [C.c_void_p]
         for f in ("p3o_encode_fwd", "p3o_encode_rc"):
             getattr(L, f).argtypes = [C.c_char_p, C.c_int, _u64p]
@@ -216,6 +219,23 @@ class Oracle:
         self.lib.p3o_free(txt)
         return s, dict(junctions=nj.value, joints=njo.value, straights=ns.value)
 
+    def dbg_joints(self, reads, bloom_words, m, H, seeds, k, min_len=None):
+        """G5: [(joint k-mer in its smaller orientation, JointInfo::coverage)] sorted (src/DeBruijnGraph.cpp:441-449)"""
+        bases, offs = _flat(reads)
+        min_len = k if min_len is None else min_len
+        nw = nwords(k)
+        sk = np.zeros(max(1, len(seeds)) * nw, np.uint64)
+        for i, sd in enumerate(seeds):
+            sk[i * nw:(i + 1) * nw] = self.encode_fwd(sd)
+        txt, ln, jt, jl = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        rc = self.lib.p3o_dbg_joints(bases, offs, offs.size - 1, min_len, k, np.ascontiguousarray(bloom_words, np.uint64), m, H,
+                                     sk, len(seeds), C.byref(txt), C.byref(ln), C.byref(jt), C.byref(jl))
+        assert rc == 0, rc
+        s = C.string_at(jt.value, jl.value).decode()
+        self.lib.p3o_free(txt)
+        self.lib.p3o_free(jt)
+        return [(a, int(b)) for a, b in (line.split("\t") for line in s.splitlines())]
+
     def refshaped_pass(self, reads, k, m, H, min_len=None, want_bloom=False):
         bases, offs = _flat(reads)
         min_len = k if min_len is None else min_len
@@ -257,6 +277,8 @@ class RefLib:
                                     C.POINTER(C.c_uint64)]
         L.p3ref_last_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.p3ref_assemble.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_char_p]
+        L.p3ref_joints.restype = C.c_uint64
+        L.p3ref_joints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
         L.p3ref_kat.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_int, _u64p, _u64p, _u64p, _u64p,
                                 C.POINTER(C.c_uint64), _u64p, _u64p]
         L.p3ref_hash_words.argtypes = [_u64p, C.c_uint64, C.c_int, _u64p, _u64p, _u64p]
@@ -371,13 +393,23 @@ class RefLib:
         finally:
             self.lib.p3ref_close(h)
 
-    def assemble_gfa(self, reads, k, m, H, threads, workdir):
+    def assemble_gfa(self, reads, k, m, H, threads, workdir, joints=False):
+        """GFA text of the real Assemble<B>; joints=True: also [(joint k-mer in its smaller orientation,
+        JointInfo::coverage)] sorted -- a field the reference fills (src/DeBruijnGraph.cpp:441-449) but never prints"""
         bases, offs = _flat(reads)
         h = self.lib.p3ref_open(bases, offs, offs.size - 1, k)
+        jl = None
         try:
             rc = self.lib.p3ref_assemble(h, k, m, H, threads, workdir.encode())
             assert rc == 0, rc
+            if joints:
+                n = self.lib.p3ref_joints(h, k, None, None, 0)
+                km = np.zeros(max(1, n * k), np.uint8)
+                cv = np.zeros(max(1, n), np.int32)
+                self.lib.p3ref_joints(h, k, km.ctypes.data, cv.ctypes.data, n)
+                jl = [(km[i * k:(i + 1) * k].tobytes().decode(), int(cv[i])) for i in range(n)]
         finally:
             self.lib.p3ref_close(h)
         with open(os.path.join(workdir, "de_bruijn_graph.gfa")) as f:
-            return f.read()
+            gfa = f.read()
+        return (gfa, jl) if joints else gfa

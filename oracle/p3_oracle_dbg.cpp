@@ -94,10 +94,15 @@ extern "C" {
 
 void p3o_free(char* p) { delete[] p; }
 
+}  // extern "C"
+
 // Returns the GFA text (reference format) in a new[]-allocated buffer (*out_text, *out_len); 0 on success.
-int p3o_dbg(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
-            const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
-            char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights) {
+// joints_out (optional): "KMER\tcoverage\n" per joint, k-mer in its smaller orientation, sorted -- JointInfo::coverage
+// (src/DeBruijnGraph.cpp:24-28,441-449), which the reference fills but never prints.
+static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+                    const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
+                    char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights,
+                    std::string* joints_out) {
   if (k < 21 || k > 64) return 2;
   Ctx cx;
   cx.k = k;
@@ -220,6 +225,11 @@ int p3o_dbg(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32
       Node* jb = junction_at(bw);
       if (jf) jf->coverage++;
       if (jb) jb->coverage++;
+      {  // joints.find(kmer_Fw) / joints.find(kmer_Bw) (:445-447): the map holds the joint in ONE orientation, so a
+         // window counts once -- twice when it is its own reverse complement
+        auto it = nodes.find(fw < bw ? fw : bw);
+        if (it != nodes.end() && it->second.joint) it->second.coverage += (fw == bw) ? 2 : 1;
+      }
       const char nxt = (i + 1 < L) ? s[i + 1] : '\0';
       if (i + 1 == (uint64_t)k) {  // first window (:407-413): reads read[k] unguarded
         if (jf) jf->rcov[fcode(nxt)]++;
@@ -301,6 +311,37 @@ int p3o_dbg(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32
   if (n_junctions) *n_junctions = (uint64_t)junction_id;
   if (n_joints) *n_joints = joint_of.size();
   if (n_straights) *n_straights = straights.size();
+  if (joints_out) {
+    std::vector<std::pair<std::string, int>> jl;
+    for (auto& kv : nodes)
+      if (kv.second.joint) jl.push_back({cx.str(kv.first), kv.second.coverage});  // (map key = canonical = smaller)
+    std::sort(jl.begin(), jl.end());
+    for (auto& j : jl) *joints_out += j.first + "\t" + std::to_string(j.second) + "\n";
+  }
+  return 0;
+}
+
+extern "C" {
+
+int p3o_dbg(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+            const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
+            char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights) {
+  return dbg_impl(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len, n_junctions,
+                  n_joints, n_straights, nullptr);
+}
+
+// as p3o_dbg, plus the joint list as text (*joints_text, new[]-allocated)
+int p3o_dbg_joints(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+                   const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
+                   char** out_text, uint64_t* out_len, char** joints_text, uint64_t* joints_len) {
+  std::string jt;
+  int rc = dbg_impl(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len, nullptr, nullptr,
+                    nullptr, &jt);
+  if (rc) return rc;
+  char* buf = new char[jt.size() + 1];
+  std::memcpy(buf, jt.data(), jt.size() + 1);
+  *joints_text = buf;
+  *joints_len = jt.size();
   return 0;
 }
 

@@ -52,6 +52,8 @@ struct Session {
   ReadFile* reads = nullptr;
   std::set<std::string> seeds;
   double t_count = 0, t_bloom = 0;
+  // joints of the last p3ref_assemble: (k-mer in its smaller orientation, JointInfo::coverage), sorted
+  std::vector<std::pair<std::string, int>> joints;
 };
 
 void fill_reads(Session& s, const char* bases, const uint64_t* offsets, uint64_t n_reads, int k) {
@@ -120,6 +122,16 @@ int assemble_t(Session& s, int k, uint64_t m, int H, int threads, const char* wo
   dbg.MakeDBG(seedkmer, m, (uint8_t)H, threads);
   dbg.CountNodeCoverage(s.reads->reads);
   dbg.PrintGraph();
+  // JointInfo::coverage (src/DeBruijnGraph.cpp:24-28, filled by AddNodeCoverage :441-449) is never printed: keep it,
+  // keyed by the joint k-mer in its smaller orientation (the map holds it as discovered)
+  s.joints.clear();
+  for (auto& kv : dbg.joints) {
+    B key = kv.first;
+    B rc = GetComplementKmer<B>(key);
+    std::string a = GetStringKmer<B>(key), b = GetStringKmer<B>(rc);
+    s.joints.push_back({a < b ? a : b, kv.second.coverage});
+  }
+  std::sort(s.joints.begin(), s.joints.end());
   if (chdir(old) != 0) return 4;
   return 0;
 }
@@ -247,6 +259,16 @@ int p3ref_assemble(void* h, int k, uint64_t m, int H, int threads, const char* w
 #undef X
     default: return 2;
   }
+}
+
+// joints of the last p3ref_assemble (k characters each, coverage), sorted by k-mer
+uint64_t p3ref_joints(void* h, int k, char* kmers, int32_t* coverage, uint64_t cap) {
+  Session* s = (Session*)h;
+  for (uint64_t i = 0; i < s->joints.size() && i < cap; i++) {
+    std::memcpy(kmers + i * k, s->joints[i].first.data(), k);
+    coverage[i] = s->joints[i].second;
+  }
+  return s->joints.size();
 }
 
 // The real loader (ReadFile ctor + LoadFile, src/Load.cpp:23-103) on a file.  Returns a session like p3ref_open;

@@ -94,6 +94,7 @@ def load(build=False):
     L.p3_export_junctions.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]
     L.p3_export_edges.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+    L.p3_export_joints.argtypes = [vp, vp, u64, C.POINTER(u64)]
     L.p3_write_gfa.argtypes = [vp, C.c_char_p]
     L.p3_mr_config.argtypes = [vp, u32, u32]
     L.p3_mr_count_partition.argtypes = [vp]
@@ -253,6 +254,34 @@ class Context:
         self._chk(self.L.p3_export_junctions(self.h, keys.ctypes.data, cov.ctypes.data, lc.ctypes.data, rc.ctypes.data,
                                              max(1, nj), C.byref(n)))
         return keys[:nj * nw].reshape(nj, nw), cov[:nj], lc[:nj * 4].reshape(nj, 4), rc[:nj * 4].reshape(nj, 4)
+
+    def export_straights(self):
+        """straight sequences (G3 StraightInfo::sequence), in id order"""
+        g = self.graph_stats()
+        n, nb = int(g["n_straights"]), int(g["straight_bases"])
+        so = np.zeros(n + 1, np.uint64)
+        seq = np.zeros(nb + 1, np.uint8)
+        cnt = C.c_uint64()
+        self._chk(self.L.p3_export_straights(self.h, so.ctypes.data, seq.ctypes.data, n + 1, nb + 1, C.byref(cnt)))
+        return [seq[int(so[i]):int(so[i + 1])].tobytes().decode() for i in range(n)]
+
+    def export_joints(self):
+        """JointInfo::coverage, two per straight: [2i] = the joint that starts straight i's sequence, [2i+1] ends it"""
+        nj = int(self.graph_stats()["n_joints"])
+        cov = np.zeros(max(1, nj), np.int32)
+        n = C.c_uint64()
+        self._chk(self.L.p3_export_joints(self.h, cov.ctypes.data, max(1, nj), C.byref(n)))
+        return cov[:nj]
+
+    def joint_coverage(self):
+        """[(joint k-mer in its smaller orientation, coverage)] sorted: the ID-free form the tests compare"""
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        k, cov, out = self.k, self.export_joints(), []
+        for i, sq in enumerate(self.export_straights()):
+            for kmer, c in ((sq[:k], cov[2 * i]), (sq[-k:], cov[2 * i + 1])):
+                rc = kmer.encode().translate(comp)[::-1].decode()
+                out.append((min(kmer, rc), int(c)))
+        return sorted(out)
 
     # ---- multi-rank protocol (device pointers are returned as plain ints) ----------------------------
     def mr_config(self, rank, n_ranks):

@@ -23,6 +23,7 @@
 #define DBG_JOINT (1u << 12)
 #define DBG_INRUN (1u << 13)
 #define DBG_JFLIP (1u << 14)   // the straight's sequence passes this node in reverse-complement orientation
+#define DBG_JRIGHT (1u << 15)  // joint at the END of its straight's sequence (the other joint starts it)
 #define DBG_KEYED (1u << 29)  // key words are valid (2-word keys: set by the inserting lane)
 #define DBG_BUSY (1u << 30)
 #define DBG_NOSLOT (~0ULL)
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, DbgRun*
     const bool last = nf ? (ninfo & DBG_ENDL) != 0 : (ninfo & DBG_ENDR) != 0;  // end flag on the side we head to
     if (PASS == 1) {
       seq[out++] = "ACGT"[(u32)(nlo & 3)];  // the last base of the oriented neighbour
-      atomicOr(&t.info[ns], DBG_INRUN | (last ? DBG_JOINT : 0u) | (nf ? DBG_JFLIP : 0u));
+      atomicOr(&t.info[ns], DBG_INRUN | (last ? (DBG_JOINT | DBG_JRIGHT) : 0u) | (nf ? DBG_JFLIP : 0u));
       t.nid[ns] = (u32)tid;
     }
     if (last) break;
@@ -374,11 +375,13 @@ __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __restrict__ 
 
 // ---- k_dbg_coverage ------------------------------------------------------------------------------------------------
 // jcov[id*9 + 0] = coverage, [1..4] = left_kmers_cov, [5..8] = right_kmers_cov (junction stored in canonical orientation)
+// jtcov[2 * straight + 0 / 1] = JointInfo::coverage of the straight's left / right joint (:445-447: a window counts once
+// for the joint it equals in either orientation, twice when it is its own reverse complement)
 template <int NW>
 __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, const uint8_t* __restrict__ bases,
                                                       u64 n_bases, u64 n_words, DbgTab t, DbgParams p,
-                                                      u32* __restrict__ jcov) {
+                                                      u32* __restrict__ jcov, u32* __restrict__ jtcov) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
   const u64 vmask = (1ULL << (p.k - 1)) - 1;
   for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
@@ -393,6 +396,8 @@ __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw
         const bool both = kr.flo == kr.rlo && kr.fhi == kr.rhi;
         const u64 clo = fcan ? kr.flo : kr.rlo, chi = fcan ? kr.fhi : kr.rhi;
         const u64 s = node_find<NW>(t, clo, chi);
+        if (s != DBG_NOSLOT && (t.info[s] & DBG_JOINT))
+          atomicAdd(&jtcov[2 * (u64)t.nid[s] + ((t.info[s] & DBG_JRIGHT) ? 1u : 0u)], both ? 2u : 1u);
         if (s != DBG_NOSLOT && (t.info[s] & DBG_JUNCTION)) {
           u32* c = jcov + (u64)t.nid[s] * 9;
           atomicAdd(&c[0], both ? 2u : 1u);  // AddNodeCoverage(Fw) and (Bw) (:441-449)

@@ -164,7 +164,7 @@ struct p3_ctx {
   u64 sing_count[P3_MAX_RANKS] = {0};
   bool s_ready = false;
   // de Bruijn stage
-  DevBuf g_klo, g_khi, g_info, g_nid, g_f0, g_f1, g_ctr, g_jcov, g_runs, g_seqoff, g_seq, g_edges, g_jkeys;
+  DevBuf g_klo, g_khi, g_info, g_nid, g_f0, g_f1, g_ctr, g_jcov, g_jtcov, g_runs, g_seqoff, g_seq, g_edges, g_jkeys;
   u64 g_cap = 0;
   bool graphed = false;
   p3_graph_stats gstats_{};
@@ -1794,8 +1794,10 @@ int build_graph_t(p3_ctx* c) {
   // coverage (G5) and edges (G6)
   if ((rc = ensure(c, c->g_jcov, (n_junc + 1) * 9 * 4))) return rc;
   HIPCHK(c, hipMemsetAsync(c->g_jcov.p, 0, (n_junc + 1) * 9 * 4, c->stream));
+  if ((rc = ensure(c, c->g_jtcov, (2 * n_runs + 2) * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->g_jtcov.p, 0, (2 * n_runs + 2) * 4, c->stream));
   LAUNCH(c, "k_dbg_coverage", (k_dbg_coverage<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-         (const u32*)c->endm.p, c->d_bases, c->n_bases, c->n_words, t, p, (u32*)c->g_jcov.p);
+         (const u32*)c->endm.p, c->d_bases, c->n_bases, c->n_words, t, p, (u32*)c->g_jcov.p, (u32*)c->g_jtcov.p);
   const u64 edge_cap = 8 * n_junc + 8;
   if ((rc = ensure(c, c->g_edges, edge_cap * 8))) return rc;
   LAUNCH(c, "k_dbg_edges", (k_dbg_edges<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, (const u32*)c->bloom.p,
@@ -2391,6 +2393,19 @@ int p3_export_straights(p3_ctx* c, uint64_t* seq_off, char* seq, uint64_t cap_n,
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpy(seq, c->g_seq.p, nb, hipMemcpyDeviceToHost));
   }
+  return P3_OK;
+}
+
+int p3_export_joints(p3_ctx* c, int32_t* coverage, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 nj = c->gstats_.n_joints;  // two per straight: [2 i] = left joint (first k-mer of the sequence), [2 i + 1] = right
+  *n = nj;
+  if (cap < nj) return fail(c, P3_ECAPACITY, "need %llu joint slots", (unsigned long long)nj);
+  if (nj == 0) return P3_OK;
+  if (!coverage) return fail(c, P3_EBADARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(coverage, c->g_jtcov.p, nj * 4, hipMemcpyDeviceToHost));
   return P3_OK;
 }
 

@@ -41,7 +41,10 @@ int run(ReadFile& input_reads, int k, uint64_t m, int H, const std::string& out)
   std::ofstream fg(out + ".graph");
   long long covsum = 0;
   for (const auto& kv : first_dbg.junctions) covsum += kv.second.coverage;
-  fg << first_dbg.junctions.size() << " " << first_dbg.joints.size() << " " << first_dbg.straights.size() << " " << covsum << "\n";
+  long long jointsum = 0;  // JointInfo::coverage (src/DeBruijnGraph.cpp:445-447)
+  for (const auto& kv : first_dbg.joints) jointsum += kv.second.coverage;
+  fg << first_dbg.junctions.size() << " " << first_dbg.joints.size() << " " << first_dbg.straights.size() << " " << covsum << " "
+     << jointsum << "\n";
   return 0;
 }
 

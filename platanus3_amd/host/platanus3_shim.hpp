@@ -491,6 +491,18 @@ class DeBruijnGraph {
         j.right_kmers_cov[b] = rcov_[i * 4 + b];
       }
     }
+    // JointInfo::coverage (AddNodeCoverage, :445-447): two per straight, in straight order
+    p3_ctx* ctx = p3shim::Session::get().context();
+    std::vector<int32_t> jc(2 * (size_t)straight_nodes_id + 1);
+    uint64_t nj = 0;
+    p3shim::check(ctx, p3_export_joints(ctx, jc.data(), jc.size(), &nj), "p3_export_joints");
+    for (auto& kv : straights) {
+      const size_t i = (size_t)kv.first - 1;
+      if (2 * i + 1 < nj) {
+        kv.second.left_joint->coverage = jc[2 * i];
+        kv.second.right_joint->coverage = jc[2 * i + 1];
+      }
+    }
   }
 
   // PrintGraph (:451-544): ./de_bruijn_graph.gfa, same format; ids are the device's

@@ -8,7 +8,7 @@ import pytest
 import platanus3_amd.synth as synth
 from platanus3_amd import capi
 from gfa_canon import canonical
-from test_oracle_dbg import check_against_golden, dbg_cases, load_dbg_reads
+from test_oracle_dbg import check_against_golden, check_joints, dbg_cases, load_dbg_reads
 
 pytestmark = pytest.mark.gpu
 
@@ -35,6 +35,7 @@ def test_graph_matches_reference_gfa(ctx, tmp_path, case):
     gfa, st = gpu_gfa(ctx, b, off, case["k"], case["m"], case["H"], tmp_path)
     assert st["n_junctions"] == case["n_junctions"] and st["n_straights"] == case["n_straights"]
     check_against_golden(case, gfa)
+    check_joints(case["name"], ctx.joint_coverage())  # G5: JointInfo::coverage
 
 
 @pytest.mark.parametrize("k,n,m,H", [(31, 20000, None, None), (27, 5000, 1 << 22, 10), (45, 5000, 1 << 23, 10),
@@ -52,6 +53,7 @@ def test_graph_vs_oracle(ctx, oracle, tmp_path, k, n, m, H):
     wn, we = canonical(want)
     assert gn == wn
     assert ge == we
+    assert ctx.joint_coverage() == oracle.dbg_joints((b, off), words, m, H, seeds, k)
 
 
 def test_dense_filter_is_refused_not_hung(ctx):

@@ -75,5 +75,8 @@ def test_shim_full_assemble_gfa(tmp_path, name):
     subprocess.check_call([exe, fa, str(case["k"]), str(case["m"]), str(case["H"]), out, "graph"], cwd=str(tmp_path),
                           timeout=120)
     check_against_golden(case, open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
-    nj, njo, ns, covsum = [int(x) for x in open(out + ".graph").read().split()]
+    nj, njo, ns, covsum, jointsum = [int(x) for x in open(out + ".graph").read().split()]
     assert nj == case["n_junctions"] and ns == case["n_straights"] and njo <= 2 * ns
+    # JointInfo::coverage materialised into the shim's joints map == what the real reference accumulated
+    gj = json.load(open(os.path.join(GOLDEN, "dbg_joints.json")))[name]
+    assert njo == gj["n"] and jointsum == gj["coverage_sum"]

@@ -51,3 +51,29 @@ def test_oracle_dbg_matches_reference_gfa(oracle, case):
     gfa, st = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
     assert st["junctions"] == case["n_junctions"] and st["straights"] == case["n_straights"]
     check_against_golden(case, gfa)
+
+
+def joint_golden(name):
+    with open(os.path.join(GOLDEN, "dbg_joints.json")) as f:
+        return json.load(f)[name]
+
+
+def check_joints(name, joints):
+    """joints: [(joint k-mer in its smaller orientation, JointInfo::coverage)] sorted"""
+    g = joint_golden(name)
+    lines = ["%s\t%d" % (a, b) for a, b in joints]
+    assert len(joints) == g["n"] and sum(b for _, b in joints) == g["coverage_sum"]
+    if "lines" in g:
+        assert lines == g["lines"]
+    assert hashlib.sha256("\n".join(lines).encode()).hexdigest() == g["sha256"]
+
+
+@pytest.mark.parametrize("case", dbg_cases(), ids=lambda c: c["name"])
+def test_oracle_joint_coverage_matches_reference(oracle, case):
+    """G5: JointInfo::coverage (src/DeBruijnGraph.cpp:441-449), a field the reference fills but never prints, against
+    what the real reference accumulated (tests/golden/make_golden_joints.py)"""
+    b, off = load_dbg_reads(case["name"])
+    k, m, H = case["k"], case["m"], case["H"]
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    check_joints(case["name"], oracle.dbg_joints((b, off), words, m, H, seeds, k))
