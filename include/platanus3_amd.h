@@ -116,7 +116,10 @@ int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
  * large_kmer_length = k), so pass min_len = k to reproduce the reference.  Copies host -> HBM. */
 int p3_load_reads(p3_ctx* ctx, const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len);
 /* Same, but `d_bases`/`d_offsets` are DEVICE pointers already resident in HBM (1 B/base ASCII +
- * uint64 offsets); nothing is copied -- the buffers must outlive the context's use of them. */
+ * uint64 offsets); nothing is copied -- the buffers must outlive the context's use of them AND MUST NOT CHANGE while
+ * they are loaded: passes over loaded reads reuse what earlier passes learnt about them (splits, sizes).  After
+ * refilling the buffers call p3_load_reads_device again (it is cheap: two 8-byte reads of the offset table's ends,
+ * which must span total_bases).  Offsets are expected non-decreasing, as p3_load_reads' are. */
 int p3_load_reads_device(p3_ctx* ctx, const void* d_bases, const void* d_offsets, uint64_t n_reads,
                          uint64_t total_bases, uint32_t min_len);
 

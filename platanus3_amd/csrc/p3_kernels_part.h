@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   // (bits 62..32) times at the sender", clear = one instance at window position (bits 62..32).
   // mode & P3_K2_AGG_OUT (POS only): emit such records instead of the table (the sender side of the above).
   const bool weighted = POS && (mode & P3_K2_WEIGHTED);
-  // gstats[29] is raised when this table took in 2^32 instances or more (weights included): only then could one of its
+  // gstats[32] is raised when this table took in 2^32 instances or more (weights included): only then could one of its
   // u32 counters have wrapped, which the max_count >= 2^31 test of the host (the reference's RMQ truncates through
   // int, src/MakeBloomFilter.cpp:11,18) would not see.  Asked for by the host when that many instances exist at all.
   const bool sumcheck = POS && (mode & P3_K2_SUMCHECK);
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (sumcheck && (((u64)sc[11] << 32) | sc[10]) >= (1ULL << 32)) gstats[29] = 1;
+    if (sumcheck && (((u64)sc[11] << 32) | sc[10]) >= (1ULL << 32)) gstats[32] = 1;
     if (s_ovf) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
     const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)s_ndist);
     s_base_lo = (u32)base;

@@ -38,6 +38,7 @@
 #include "p3_kernels_bloom.h"
 #include "p3_kernels_retgate.h"
 #include "p3_kernels_sk.h"
+#include "p3_kernels_seedset.h"
 #include "p3_kernels_dbg.h"
 
 namespace {
@@ -196,6 +197,11 @@ struct p3_ctx {
   int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
   DevBuf unk_flag;           // set by k_pack when a base is not A/C/G/T
 
+  // the seed SET on the device (p3_kernels_seedset.h): 2^seedset_bbits sorted runs of distinct keys, ocap slots each
+  DevBuf seed_part, seed_hist, seed_set, seed_ucount, seed_flag;
+  u32 seedset_bbits = 0, seedset_ocap = 0;
+  bool seedset_ready = false;  // (checked against seed_flag at the pass's synchronisation)
+
   // bloom
   DevBuf bloom, seeds, seed_valid;
   u32 k = 0, H = 0;
@@ -210,6 +216,7 @@ struct p3_ctx {
 namespace {
 
 constexpr int P3_ERETRY_INTERNAL = 1000;  // never crosses the ABI
+constexpr int P3_NSTAT = 40;                // u64 words of the device statistics / flag block (dstats)
 
 int fail(p3_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -461,7 +468,7 @@ int do_count_direct(p3_ctx* c) {
   if ((rc = ensure(c, c->tcounts, cap * 8))) return rc;
   HIPCHK(c, hipMemsetAsync(c->tkeys.p, 0xff, cap * 8, c->stream));
   HIPCHK(c, hipMemsetAsync(c->tcounts.p, 0, cap * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, P3_NSTAT * 8, c->stream));
   u64* st = (u64*)c->dstats.p;
   LAUNCH(c, "k_count_direct", k_count_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
          (const u32*)c->endm.p, c->n_words, (u64*)c->tkeys.p, (u64*)c->tcounts.p, cap - 1, st + 3);
@@ -476,7 +483,7 @@ int do_count_direct(p3_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
+  c->cstats.max_count = h[2];
   c->cstats.n_windows = h[3];
   c->count_mode = 1;
   c->gate_mode = 1;
@@ -608,7 +615,7 @@ int part_local(p3_ctx* c, bool with_pos) {
     if ((rc = ensure(c, c->part, max_records * 4))) return rc;
   }
   u64* st = (u64*)c->dstats.p;
-  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, 32 * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->dstats.p, 0, P3_NSTAT * 8, c->stream));
   const size_t lds8 = (size_t)P3_STAGE_WORDS * 4;
   c->part_sk = false;
   if (est && sk_on(c)) {
@@ -755,7 +762,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if ((rc = set_k2ext(c, maxd, c->n_ranks > 1 ? c->rx_roff.p : nullptr, c->n_ranks))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 29, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
   const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
   if (c->part_sk) {
     if (sbits < c->sk_fbits) return fail(c, P3_EHIP, "run records: split %u below the scattered fine buckets %u", sbits, c->sk_fbits);
@@ -803,7 +810,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     *max_solid_sb = 0;
     return P3_OK;
   }
-  u64 h[32];
+  u64 h[P3_NSTAT];
   u32 unk[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   if (c->part_sk) HIPCHK(c, hipMemcpyAsync(unk, c->unk_flag.p, 16, hipMemcpyDeviceToHost, c->stream));
@@ -825,7 +832,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
+  c->cstats.max_count = h[32] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[32]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];  // this rank's windows (local partition)
   c->ccounts_u32 = true;
   return P3_OK;
@@ -858,7 +865,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
   HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 29, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 31, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
@@ -916,7 +923,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
     *max_solid_sb = 0;
     return P3_OK;
   }
-  u64 h[32];
+  u64 h[P3_NSTAT];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h[26] || h[27]) {
@@ -932,7 +939,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
   c->cstats.n_solid = h[1];
-  c->cstats.max_count = h[29] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[29]: a u32 counter may have wrapped)
+  c->cstats.max_count = h[32] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[32]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];
   return P3_OK;
 }
@@ -1227,7 +1234,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
       if ((rc = part_local(c, true))) return rc;
       HIPCHK(c, hipMemcpyAsync((char*)c->rx_ghist_buf.p + ci * desc, c->ghist.p, desc, hipMemcpyDeviceToDevice, c->stream));
       HIPCHK(c, hipMemcpyAsync((char*)c->rx_segoff_buf.p + ci * desc, c->seg_off.p, desc, hipMemcpyDeviceToDevice, c->stream));
-      u64 h[32];
+      u64 h[P3_NSTAT];
       HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (h[26]) {
@@ -1278,7 +1285,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
       view.set(ci);
       if ((rc = solid_bits(c, (const u32*)c->singles.p + sroff[ci], (const u64*)c->sing_cursor.p + ci, c->sing_count[ci])))
         return rc;
-      u64 h[32];
+      u64 h[P3_NSTAT];
       HIPCHK(c, hipMemcpyAsync(h, c->dstats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (h[26]) {
@@ -1292,7 +1299,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
 
 int do_count(p3_ctx* c) {
   int rc;
-  if ((rc = ensure(c, c->dstats, 32 * 8))) return rc;
+  if ((rc = ensure(c, c->dstats, P3_NSTAT * 8))) return rc;
   c->chunks = 1;
   const u32 nch = chunks_for(c);
   if (nch) {
@@ -1317,6 +1324,41 @@ int do_count(p3_ctx* c) {
     if (c->count_mode_opt == 2) return fail(c, P3_ECAPACITY, "partitioned count forced but an LDS table overflowed");
   }
   return do_count_direct(c);
+}
+
+// std::set semantics of the seeds (src/MakeBloomFilter.cpp:79-83) on the device: sorted, duplicates removed
+template <int NW>
+int seeds_to_set(p3_ctx* c, u32 k) {
+  int rc;
+  c->seedset_ready = false;
+  if (c->n_reads == 0) return P3_OK;
+  u32 bbits = 2;
+  while (bbits < 14 && (c->n_reads >> bbits) > 1024) bbits++;  // <= ~1 Ki seeds per bucket (50 M reads: 3 Ki)
+  if (bbits > 2 * k - 2) bbits = 2 * k - 2;
+  u32 nwg = (u32)std::min<u64>(256, std::max<u64>(1, c->n_reads / 8192));
+  const double mean = (double)c->n_reads / ((double)(1u << bbits) * nwg);
+  const u32 segcap = ((u32)(2.0 * mean + 6.0 * std::sqrt(mean) + 16.0) + 15u) & ~15u;
+  const double bmean = (double)c->n_reads / (double)(1u << bbits);
+  u32 lds_keys = 1024;  // LDS sort capacity per bucket: 4x the mean, at most 128 KiB of keys
+  while (lds_keys < 4.0 * bmean && lds_keys * 8 * NW < 128 * 1024) lds_keys <<= 1;
+  const u32 ocap = lds_keys;
+  if ((rc = ensure(c, c->seed_part, ((u64)nwg << bbits) * segcap * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->seed_hist, ((u64)nwg << bbits) * 4))) return rc;
+  if ((rc = ensure(c, c->seed_set, ((u64)ocap << bbits) * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->seed_ucount, ((u64)1 << bbits) * 4))) return rc;
+  if ((rc = ensure(c, c->seed_flag, 16))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->seed_flag.p, 0, 16, c->stream));
+  LAUNCH_LDS(c, "k_seed_scatter", (k_seed_scatter<NW>), nwg, 1024, ((size_t)4 << bbits), (const u64*)c->seeds.p,
+             (const uint8_t*)c->seed_valid.p, c->n_reads, k, bbits, segcap, (u64*)c->seed_part.p, (u32*)c->seed_hist.p,
+             (u32*)c->seed_flag.p);
+  // (small buckets: 256 threads, so that several sort workgroups share a CU and a barrier costs four waves, not sixteen)
+  LAUNCH_LDS(c, "k_seed_sort", (k_seed_sort<NW>), 1u << bbits, lds_keys <= 4096 ? 256 : 1024, (size_t)lds_keys * 8 * NW, (const u64*)c->seed_part.p,
+             (const u32*)c->seed_hist.p, nwg, segcap, lds_keys, ocap, (u64*)c->seed_set.p, (u32*)c->seed_ucount.p,
+             (u32*)c->seed_flag.p);
+  c->seedset_bbits = bbits;
+  c->seedset_ocap = ocap;
+  c->seedset_ready = true;
+  return P3_OK;
 }
 
 // Bloom stage.  Gate (S bits) first, then either the direct form (H probes per passing window) or the
@@ -1637,11 +1679,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     c->bloom_mode = 1;
   }
   HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  if (c->chunks == 1)  // (position chunks: the seeds need the pass bits of ALL chunks; bloom_chunked runs them at the end)
+  if (c->chunks == 1) {  // (position chunks: the seeds need the pass bits of ALL chunks; bloom_chunked runs them at the end)
     LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
            (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+    if ((rc = seeds_to_set<NW>(c, k))) return rc;
+  }
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-  u64 hall[32];
+  u64 hall[P3_NSTAT];
   u32 unk[4] = {0, 0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(hall, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
   if (c->spec && c->part_pos)
@@ -1669,9 +1713,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (c->spec) {
     // the single synchronisation point of a speculative pass: were last pass's splits still good?
     if (hall[3] || hall[16 + 3]) return fail(c, P3_ERETRY_INTERNAL, "an LDS table overflowed under the previous split");
+    // (second-level partition of the count stage: its sampled layout and the size of the table outputs are checked by
+    // count_split only on the careful path)
+    if (hall[31] || (c->split_xbits && hall[27]))
+      return fail(c, P3_ERETRY_INTERNAL, "count stage: outputs or per-cell layout too small under the previous sizes");
     c->cstats.n_distinct = hall[0];
     c->cstats.n_solid = hall[1];
-    c->cstats.max_count = hall[29] ? std::max<u64>(hall[2], 1ull << 32) : hall[2];
+    c->cstats.max_count = hall[32] ? std::max<u64>(hall[2], 1ull << 32) : hall[2];
     c->cstats.n_windows = hall[5];
     c->n_distinct_k = hall[16];
     if (c->cstats.max_count >= (1ULL << 31))
@@ -1894,6 +1942,7 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
   HIPCHK(c, hipMemsetAsync(st + 10, 0, 8, c->stream));
   LAUNCH(c, "k_seeds", (k_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
          (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  if ((rc = seeds_to_set<NW>(c, k))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 ns = 0;
   HIPCHK(c, hipMemcpyAsync(&ns, st + 10, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2130,7 +2179,14 @@ int p3_load_reads_device(p3_ctx* c, const void* d_bases, const void* d_offsets, 
   if (!c) return P3_EBADARG;
   if (!d_offsets || (total_bases && !d_bases)) return fail(c, P3_EBADARG, "null device pointers");
   HIPCHK(c, hipSetDevice(c->device));
-  c->d_bases = (const uint8_t*)d_bases;
+  // the two ends of the offset table must describe total_bases (the kernels index the base buffer with them)
+  u64 ends[2] = {0, 0};
+  HIPCHK(c, hipMemcpy(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(&ends[1], (const u64*)d_offsets + n_reads, 8, hipMemcpyDeviceToHost));
+  if (ends[1] < ends[0] || ends[1] - ends[0] != total_bases)
+    return fail(c, P3_EBADARG, "offsets[0] = %llu, offsets[n_reads] = %llu do not span total_bases = %llu",
+                (unsigned long long)ends[0], (unsigned long long)ends[1], (unsigned long long)total_bases);
+  c->d_bases = (const uint8_t*)d_bases + ends[0];
   c->d_offsets = (const u64*)d_offsets;
   return set_reads_common(c, n_reads, total_bases, min_len);
 }
@@ -2154,7 +2210,7 @@ int p3_mr_count_partition(p3_ctx* c) {
   if (!part_applicable(c)) return fail(c, P3_ECAPACITY, "input too large for the partitioned count (multi-rank needs it)");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = ensure(c, c->dstats, 32 * 8))) return rc;
+  if ((rc = ensure(c, c->dstats, P3_NSTAT * 8))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if ((rc = do_pack(c))) return rc;
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -2584,6 +2640,30 @@ int p3_export_seeds(p3_ctx* c, uint64_t* fwd_keys, uint64_t cap, uint64_t* n) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "no seeds yet");
   HIPCHK(c, hipSetDevice(c->device));
   const int nw = nw_of(c->k);
+  if (c->seedset_ready) {
+    // the set was built inside the pass (p3_kernels_seedset.h): 2^bbits sorted runs of distinct keys -- a copy
+    u32 flag[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpy(flag, c->seed_flag.p, 16, hipMemcpyDeviceToHost));
+    if (!flag[0]) {
+      const u32 nb = 1u << c->seedset_bbits;
+      std::vector<u32> uc(nb);
+      HIPCHK(c, hipMemcpy(uc.data(), c->seed_ucount.p, (size_t)nb * 4, hipMemcpyDeviceToHost));
+      u64 total = 0;
+      for (u32 b = 0; b < nb; b++) total += uc[b];
+      *n = total;
+      if (cap < total) return fail(c, P3_ECAPACITY, "need %llu seed slots", (unsigned long long)total);
+      if (total && !fwd_keys) return fail(c, P3_EBADARG, "null output");
+      u64 at = 0;
+      for (u32 b = 0; b < nb; b++) {
+        if (!uc[b]) continue;
+        HIPCHK(c, hipMemcpy(fwd_keys + at * nw, (const u64*)c->seed_set.p + (u64)b * c->seedset_ocap * nw, (size_t)uc[b] * 8 * nw,
+                            hipMemcpyDeviceToHost));
+        at += uc[b];
+      }
+      return P3_OK;
+    }
+    // (a capacity estimate did not hold: the per-read form below)
+  }
   std::vector<u64> h((size_t)c->n_reads * nw);
   std::vector<uint8_t> hv((size_t)c->n_reads);
   if (c->n_reads) {
@@ -2657,7 +2737,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     c->spec = true;
     rc = P3_OK;
     do {
-      if ((rc = ensure(c, c->dstats, 32 * 8))) break;
+      if ((rc = ensure(c, c->dstats, P3_NSTAT * 8))) break;
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       if ((rc = do_pack(c))) break;
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));

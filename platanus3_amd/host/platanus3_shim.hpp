@@ -81,8 +81,10 @@ struct Session {
   p3_ctx* ctx = nullptr;
   const ReadSet* loaded = nullptr;
   size_t loaded_size = 0;
+  uint64_t loaded_print = 0;   // content fingerprint of the ReadSet that is resident on the device
   uint32_t loaded_min_len = 0;
   bool counted = false;
+  uint64_t kc_size = 0, kc_print = 0;  // the KmerCount CountShortKmer materialised (MakeBF checks it was not edited)
   static Session& get() {
     static Session s;
     return s;
@@ -92,8 +94,36 @@ struct Session {
     return ctx;
   }
   // flat form of the ReadSet (T1).  The loader's length filter (src/Load.cpp:59) is applied by the library.
+  // every base and every length of the set, in iteration order (a caller may edit reads in place between the calls)
+  static uint64_t fingerprint(const ReadSet& rs) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ rs.size();
+    for (const auto& kv : rs) {
+      const std::string& q = kv.second;
+      h = (h ^ q.size()) * 0xff51afd7ed558ccdULL;
+      size_t i = 0;
+      for (; i + 8 <= q.size(); i += 8) {
+        uint64_t w;
+        std::memcpy(&w, q.data() + i, 8);
+        h = (h ^ w) * 0xc4ceb9fe1a85ec53ULL;
+        h ^= h >> 29;
+      }
+      for (; i < q.size(); i++) h = (h ^ (unsigned char)q[i]) * 0x100000001b3ULL;
+    }
+    return h;
+  }
+  template <typename KC>
+  static uint64_t kc_fingerprint(const KC& kc) {  // the first entries in iteration order (stable while the map is untouched)
+    uint64_t h = kc.size(), n = 0;
+    for (const auto& kv : kc) {
+      h = (h ^ kv.first.to_ullong() ^ (kv.second << 43)) * 0xff51afd7ed558ccdULL;
+      if (++n == 4096) break;
+    }
+    return h;
+  }
   void load(const ReadSet& rs, uint32_t min_len) {
-    if (loaded == &rs && loaded_size == rs.size() && loaded_min_len == min_len) return;
+    const uint64_t print = fingerprint(rs);
+    if (loaded == &rs && loaded_size == rs.size() && loaded_min_len == min_len && loaded_print == print) return;
+    loaded_print = print;
     std::string bases;
     std::vector<uint64_t> offs;
     offs.reserve(rs.size() + 1);
@@ -287,6 +317,8 @@ class ReadFile {
     db.reserve(n);
     for (uint64_t i = 0; i < n; i++) db.emplace(std::bitset<42>(keys[i]), counts[i]);
     shortk_database.swap(db);
+    s.kc_size = shortk_database.size();
+    s.kc_print = p3shim::Session::kc_fingerprint(shortk_database);
   }
 };
 
@@ -365,12 +397,19 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
   p3_ctx* ctx = s.context();
   // The device-resident count table is reused when CountShortKmer was just run on the same ReadSet; KC itself
   // is the materialised copy of that table (the gate is evaluated against the device copy).
-  if (!(s.loaded == &RS && s.counted)) {
+  // (load() compares a content fingerprint, so reads edited in place since CountShortKmer are uploaded and counted again)
+  const bool same_reads = s.loaded == &RS && s.loaded_size == RS.size() && s.loaded_print == p3shim::Session::fingerprint(RS);
+  if (!(same_reads && s.counted && s.loaded_min_len == (uint32_t)kmer_length)) {
     s.load(RS, (uint32_t)kmer_length);
     p3shim::check(ctx, p3_count_short(ctx), "p3_count_short");
     s.counted = true;
+  } else if (KC.size() != s.kc_size || p3shim::Session::kc_fingerprint(KC) != s.kc_print) {
+    // The reference gates on the KmerCount it is HANDED (src/MakeBloomFilter.cpp:57); here the gate runs against the
+    // device-resident table of these reads.  A caller that edited or replaced shortk_database in between would get the
+    // unedited counts: refuse loudly rather than answer for a different table.
+    throw std::invalid_argument("MakeBF: the KmerCount argument is not the table CountShortKmer produced for these reads "
+                                "(edited tables are not supported by the device path)");
   }
-  (void)KC;
   p3shim::check(ctx, p3_make_bloom(ctx, (uint32_t)kmer_length, filtersize, numhashes), "p3_make_bloom");
   BF<LARGE_BITSET> bf(filtersize, numhashes);
   std::vector<uint64_t> words((filtersize + 63) / 64);
@@ -400,7 +439,7 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
 // :451 PrintGraph.  The traversal, classification, coverage and link emission run on the device (p3_build_graph); the
 // three maps are materialised from its flat exports.  Ids are assigned by the device (the reference's own ids depend on
 // its thread count); keys are stored in canonical orientation (the reference stores "as discovered" and always looks
-// up both orientations, :302-309).  JointInfo::coverage is never printed by the reference and is left 0.
+// up both orientations, :302-309).  JointInfo::coverage (never printed by the reference) is filled by CountNodeCoverage.
 struct StraightInfo;
 struct JunctionInfo {
   int id;
