@@ -42,7 +42,9 @@ def build_lib(force=False, verbose=False):
     srcs, deps = _hip_sources()
     if not (force or _newer(LIB, srcs + deps)):
         return LIB
-    objs = []
+    # the translation units are independent: compile them side by side (hipcc is single-threaded per unit)
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
     for src in srcs:
         obj = os.path.splitext(src)[0] + ".o"
         if src.endswith(".hip"):
@@ -50,10 +52,16 @@ def build_lib(force=False, verbose=False):
                    "-I" + INCLUDE, "-I" + CSRC, "-c", "-o", obj, src]
         else:  # plain C (the synthetic-read generator)
             cmd = ["gcc", "-O3", "-fPIC", "-I" + INCLUDE, "-c", "-o", obj, src]
+        jobs.append((cmd, obj))
+
+    def run(job):
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+            print(" ".join(job[0]))
+        subprocess.check_call(job[0])
+        return job[1]
+
+    with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        objs = list(ex.map(run, jobs))
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))

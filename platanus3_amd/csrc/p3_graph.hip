@@ -1,0 +1,264 @@
+// p3_graph.hip -- G3-G6 DeBruijnGraph (src/DeBruijnGraph.cpp:93-544): MakeDBG, CountNodeCoverage, PrintGraph and the exports (gfx950 only).
+#include "p3_ctx.h"
+#include "p3_kernels_dbg.h"
+using namespace p3i;
+
+namespace {
+
+// ---- de Bruijn stage (G3-G6) -------------------------------------------------------------------------------------
+template <int NW>
+int build_graph_t(p3_ctx* c) {
+  int rc;
+  const u32 k = c->k;
+  DbgParams p;
+  p.k = k;
+  p.H = c->H;
+  p.mm = make_modm(c->m);
+  if (NW == 1) {
+    p.mask_lo = (2 * k == 64) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    p.mask_hi = 0;
+  } else {
+    p.mask_lo = ~0ULL;
+    p.mask_hi = (2 * k == 128) ? ~0ULL : ((1ULL << (2 * k - 64)) - 1);
+  }
+  if ((rc = ensure(c, c->g_ctr, 16 * 8))) return rc;
+  u64* ctr = (u64*)c->g_ctr.p;
+  // table capacity: a few times the number of distinct inserted k-mers (false-positive neighbours add nodes)
+  u64 est = c->n_distinct_k ? c->n_distinct_k : c->bstats.n_passing;
+  if (est > c->n_bases) est = c->n_bases;
+  if (est < c->bstats.n_seed_reads) est = c->bstats.n_seed_reads;
+  u64 cap = 1 << 12;
+  while (cap < 3 * est + 4096) cap <<= 1;
+  u64 hc[16];
+  u64 levels = 0;
+  for (int attempt = 0;; attempt++) {
+    // The closure is bounded only by the filter's false-positive rate: with a dense filter (the reference's default
+    // sizing reaches ~90 % set bits on small inputs) false neighbours breed faster than they die out and the node set
+    // grows without limit (the reference itself does not terminate there).  Refuse beyond 64x the estimate.
+    if (attempt > 3)
+      return fail(c, P3_ECAPACITY, "de Bruijn closure exceeds %llu nodes: Bloom filter too dense for a finite graph",
+                  (unsigned long long)(cap / 8));
+    c->g_cap = cap;
+    const u64 node_limit = cap / 2 + cap / 8;  // 62 % load at most
+    const u64 fcap = 8 * node_limit + 64;       // every inserted node appends at most 8 neighbours
+    if ((rc = ensure(c, c->g_klo, cap * 8))) return rc;
+    if (NW == 2 && (rc = ensure(c, c->g_khi, cap * 8))) return rc;
+    if ((rc = ensure(c, c->g_info, cap * 4))) return rc;
+    if ((rc = ensure(c, c->g_nid, cap * 4))) return rc;
+    if ((rc = ensure(c, c->g_f0, fcap * 8 * NW))) return rc;
+    if ((rc = ensure(c, c->g_f1, fcap * 8 * NW))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->g_klo.p, 0xff, cap * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->g_info.p, 0, cap * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->g_nid.p, 0, cap * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(ctr, 0, 16 * 8, c->stream));
+    DbgTab t{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
+    // level 0: the per-read seed keys (MakeDBG iterates the seed set, :96-105)
+    const u64* fin = (const u64*)c->seeds.p;
+    const uint8_t* fvalid = (const uint8_t*)c->seed_valid.p;
+    u64 n_in = c->n_reads;
+    DevBuf* outb = &c->g_f0;
+    bool overflow = false;
+    levels = 0;
+    while (n_in) {
+      HIPCHK(c, hipMemsetAsync(ctr, 0, 8, c->stream));
+      LAUNCH(c, "k_dbg_expand", (k_dbg_expand<NW>), grid_for(n_in, 256, 1u << 30), 256, fin, fvalid, n_in, (u64*)outb->p,
+             fcap, t, (const u32*)c->bloom.p, p, node_limit, ctr);
+      HIPCHK(c, hipMemcpyAsync(hc, ctr, 3 * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (hc[2]) {
+        overflow = true;
+        break;
+      }
+      fin = (const u64*)outb->p;
+      fvalid = nullptr;
+      n_in = hc[0];
+      outb = (outb == &c->g_f0) ? &c->g_f1 : &c->g_f0;
+      levels++;
+    }
+    if (!overflow) break;
+    cap <<= 2;
+  }
+  const u64 n_nodes = hc[1];
+  DbgTab t{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
+  LAUNCH(c, "k_dbg_classify", (k_dbg_classify<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, ctr);
+  // runs: pass 0 registers them, the host lays the sequences out, pass 1 writes them
+  if ((rc = ensure(c, c->g_runs, (n_nodes / 2 + 16) * sizeof(DbgRun)))) return rc;
+  LAUNCH(c, "k_dbg_walk0", (k_dbg_walk<NW, 0>), grid_for(cap, 256, 1u << 30), 256, t, p, (DbgRun*)c->g_runs.p,
+         (const u64*)nullptr, (char*)nullptr, (u64)0, ctr, n_nodes + 2);
+  HIPCHK(c, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const u64 n_junc = hc[3], n_runs = hc[4];
+  std::vector<DbgRun> hruns(n_runs);
+  if (n_runs) HIPCHK(c, hipMemcpy(hruns.data(), c->g_runs.p, n_runs * sizeof(DbgRun), hipMemcpyDeviceToHost));
+  c->g_seqoff_host.assign(n_runs + 1, 0);
+  for (u64 i = 0; i < n_runs; i++) c->g_seqoff_host[i + 1] = c->g_seqoff_host[i] + k + hruns[i].len - 1;
+  const u64 seq_total = c->g_seqoff_host[n_runs];
+  if ((rc = ensure(c, c->g_seqoff, (n_runs + 1) * 8))) return rc;
+  if ((rc = ensure(c, c->g_seq, seq_total + 16))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->g_seqoff.p, c->g_seqoff_host.data(), (n_runs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (n_runs)
+    LAUNCH(c, "k_dbg_walk1", (k_dbg_walk<NW, 1>), grid_for(n_runs, 256, 1u << 30), 256, t, p, (DbgRun*)c->g_runs.p,
+           (const u64*)c->g_seqoff.p, (char*)c->g_seq.p, n_runs, ctr, n_nodes + 2);
+  // coverage (G5) and edges (G6)
+  if ((rc = ensure(c, c->g_jcov, (n_junc + 1) * 9 * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->g_jcov.p, 0, (n_junc + 1) * 9 * 4, c->stream));
+  if ((rc = ensure(c, c->g_jtcov, (2 * n_runs + 2) * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->g_jtcov.p, 0, (2 * n_runs + 2) * 4, c->stream));
+  LAUNCH(c, "k_dbg_coverage", (k_dbg_coverage<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, c->d_bases, c->n_bases, c->n_words, t, p, (u32*)c->g_jcov.p, (u32*)c->g_jtcov.p);
+  const u64 edge_cap = 8 * n_junc + 8;
+  if ((rc = ensure(c, c->g_edges, edge_cap * 8))) return rc;
+  LAUNCH(c, "k_dbg_edges", (k_dbg_edges<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, (const u32*)c->bloom.p,
+         (const u32*)c->g_jcov.p, (uint2*)c->g_edges.p, edge_cap, ctr);
+  if ((rc = ensure(c, c->g_jkeys, (n_junc + 1) * 8 * NW))) return rc;
+  LAUNCH(c, "k_dbg_gather", (k_dbg_gather<NW>), grid_for(cap, 256, 1u << 30), 256, t, (u64*)c->g_jkeys.p);
+  HIPCHK(c, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gstats_.n_nodes = n_nodes;
+  c->gstats_.n_junctions = n_junc;
+  c->gstats_.n_straights = n_runs;
+  c->gstats_.n_joints = 2 * n_runs;
+  c->gstats_.straight_bases = seq_total;
+  c->gstats_.n_edges = hc[5];
+  c->gstats_.levels = levels;
+  c->graphed = true;
+  return P3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int p3_build_graph(p3_ctx* c) {
+  if (!c) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
+  if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
+  HIPCHK(c, hipSetDevice(c->device));
+  return nw_of(c->k) == 1 ? build_graph_t<1>(c) : build_graph_t<2>(c);
+}
+
+int p3_get_graph_stats(p3_ctx* c, p3_graph_stats* out) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  *out = c->gstats_;
+  return P3_OK;
+}
+
+int p3_export_junctions(p3_ctx* c, uint64_t* keys, int32_t* coverage, int32_t* left_cov, int32_t* right_cov, uint64_t cap,
+                        uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 nj = c->gstats_.n_junctions;
+  *n = nj;
+  if (cap < nj) return fail(c, P3_ECAPACITY, "need %llu junction slots", (unsigned long long)nj);
+  if (!nj) return P3_OK;
+  if (!keys || !coverage || !left_cov || !right_cov) return fail(c, P3_EBADARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nw = nw_of(c->k);
+  HIPCHK(c, hipMemcpy(keys, c->g_jkeys.p, nj * 8 * nw, hipMemcpyDeviceToHost));
+  std::vector<u32> jc(nj * 9);
+  HIPCHK(c, hipMemcpy(jc.data(), c->g_jcov.p, nj * 9 * 4, hipMemcpyDeviceToHost));
+  for (u64 i = 0; i < nj; i++) {
+    coverage[i] = (int32_t)jc[i * 9];
+    for (int b = 0; b < 4; b++) {
+      left_cov[i * 4 + b] = (int32_t)jc[i * 9 + 1 + b];
+      right_cov[i * 4 + b] = (int32_t)jc[i * 9 + 5 + b];
+    }
+  }
+  return P3_OK;
+}
+
+int p3_export_straights(p3_ctx* c, uint64_t* seq_off, char* seq, uint64_t cap_n, uint64_t cap_bases, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 ns = c->gstats_.n_straights, nb = c->gstats_.straight_bases;
+  *n = ns;
+  if (cap_n < ns || cap_bases < nb) return fail(c, P3_ECAPACITY, "need %llu straights / %llu bases", (unsigned long long)ns,
+                                                (unsigned long long)nb);
+  if (!seq_off) return fail(c, P3_EBADARG, "null output");
+  for (u64 i = 0; i <= ns; i++) seq_off[i] = c->g_seqoff_host[i];
+  if (nb) {
+    if (!seq) return fail(c, P3_EBADARG, "null output");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(seq, c->g_seq.p, nb, hipMemcpyDeviceToHost));
+  }
+  return P3_OK;
+}
+
+int p3_export_joints(p3_ctx* c, int32_t* coverage, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 nj = c->gstats_.n_joints;  // two per straight: [2 i] = left joint (first k-mer of the sequence), [2 i + 1] = right
+  *n = nj;
+  if (cap < nj) return fail(c, P3_ECAPACITY, "need %llu joint slots", (unsigned long long)nj);
+  if (nj == 0) return P3_OK;
+  if (!coverage) return fail(c, P3_EBADARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpy(coverage, c->g_jtcov.p, nj * 4, hipMemcpyDeviceToHost));
+  return P3_OK;
+}
+
+int p3_export_edges(p3_ctx* c, uint32_t* a, uint32_t* b, uint64_t cap, uint64_t* n) {
+  if (!c || !n) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 ne = c->gstats_.n_edges;
+  *n = ne;
+  if (cap < ne) return fail(c, P3_ECAPACITY, "need %llu edge slots", (unsigned long long)ne);
+  if (!ne) return P3_OK;
+  if (!a || !b) return fail(c, P3_EBADARG, "null output");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<uint2> e(ne);
+  HIPCHK(c, hipMemcpy(e.data(), c->g_edges.p, ne * 8, hipMemcpyDeviceToHost));
+  for (u64 i = 0; i < ne; i++) {
+    a[i] = e[i].x;
+    b[i] = e[i].y;
+  }
+  return P3_OK;
+}
+
+// GFA 1.0 text in the reference's format (PrintGraph, src/DeBruijnGraph.cpp:451-544); ids are ours.
+int p3_write_gfa(p3_ctx* c, const char* path) {
+  if (!c || !path) return P3_EBADARG;
+  if (!c->graphed) return fail(c, P3_ESTATE, "no graph yet");
+  const u64 nj = c->gstats_.n_junctions, ns = c->gstats_.n_straights, nb = c->gstats_.straight_bases, ne = c->gstats_.n_edges;
+  const int nw = nw_of(c->k), k = (int)c->k;
+  std::vector<u64> jk((nj + 1) * nw), so(ns + 1);
+  std::vector<int32_t> cov(nj + 1), lc((nj + 1) * 4), rc4((nj + 1) * 4);
+  std::vector<char> seq(nb + 1);
+  std::vector<u32> ea(ne + 1), eb(ne + 1);
+  u64 n = 0;
+  int rc;
+  if ((rc = p3_export_junctions(c, jk.data(), cov.data(), lc.data(), rc4.data(), nj + 1, &n))) return rc;
+  if ((rc = p3_export_straights(c, so.data(), seq.data(), ns + 1, nb + 1, &n))) return rc;
+  if ((rc = p3_export_edges(c, ea.data(), eb.data(), ne + 1, &n))) return rc;
+  FILE* f = std::fopen(path, "w");
+  if (!f) return fail(c, P3_EBADARG, "cannot open %s", path);
+  std::fputs("H\tVN:Z:1.0\n", f);
+  for (u64 i = 0; i < ns; i++) {
+    std::fprintf(f, "S\tStraight_%llu\t", (unsigned long long)(i + 1));
+    std::fwrite(seq.data() + so[i], 1, so[i + 1] - so[i], f);
+    std::fprintf(f, "\tKC:i:%llu\n", (unsigned long long)(so[i + 1] - so[i]));
+  }
+  std::string km((size_t)k, 'A');
+  for (u64 i = 0; i < nj; i++) {
+    for (int b = 0; b < k; b++) {
+      const int bit = 2 * (k - 1 - b);
+      km[(size_t)b] = "ACGT"[(jk[i * nw + (bit >> 6)] >> (bit & 63)) & 3];
+    }
+    std::fprintf(f, "S\tJunction_%llu\t%s\tKC:i:%lld\n", (unsigned long long)(i + 1), km.c_str(), (long long)cov[i] * k);
+  }
+  auto name = [&](u32 r, char* buf, size_t nbuf) {
+    std::snprintf(buf, nbuf, "%s_%u\t%c", (r >> 31) ? "Straight" : "Junction", (r & 0x3fffffffu) + 1, (r & (1u << 30)) ? '-' : '+');
+  };
+  char na[64], nbuf[64];
+  for (u64 i = 0; i < ne; i++) {
+    name(ea[i], na, sizeof na);
+    name(eb[i], nbuf, sizeof nbuf);
+    std::fprintf(f, "L\t%s\t%s\t%dM\n", na, nbuf, k - 1);
+  }
+  std::fclose(f);
+  return P3_OK;
+}
+
+}  // extern "C"
+

@@ -27,7 +27,7 @@ __device__ __forceinline__ u64 sk_pairs_reversed(u64 x) {
 }
 
 // ---- k_pack: ASCII -> 2-bit forward stream (MSB-first) + complement stream (LSB-first) ---------------
-__global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ bases, u64 n_bases, u64 n_words_alloc,
+static __global__ void __launch_bounds__(256) k_pack(const uint8_t* __restrict__ bases, u64 n_bases, u64 n_words_alloc,
                                               u64* __restrict__ fw, u64* __restrict__ rcw, int aligned16,
                                               u32* __restrict__ unknown_flag) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void mark_range(u32* endm, u64 lo, u64 hi) {  // [lo,
   }
 }
 
-__global__ void __launch_bounds__(256) k_endmask(const u64* __restrict__ offsets, u64 n_reads, u32 min_len,
+static __global__ void __launch_bounds__(256) k_endmask(const u64* __restrict__ offsets, u64 n_reads, u32 min_len,
                                                  u32* __restrict__ endm, u64 n_bases, u64 n_bits_alloc) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r <= n_reads; r += stride) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ u64 table_find(const u64* __restrict__ tkeys, const u
   }
 }
 
-__global__ void __launch_bounds__(256) k_count_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(256) k_count_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, u64 n_words,
                                                       u64* __restrict__ tkeys, u64* __restrict__ tcounts, u64 cap_mask,
                                                       u64* __restrict__ n_windows) {
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_count_direct(const u64* __restrict__ fw
 }
 
 // stats[0]=n_distinct stats[1]=n_solid stats[2]=max_count
-__global__ void __launch_bounds__(256) k_count_compact(const u64* __restrict__ tkeys, const u64* __restrict__ tcounts,
+static __global__ void __launch_bounds__(256) k_count_compact(const u64* __restrict__ tkeys, const u64* __restrict__ tcounts,
                                                        u64 cap, u64* __restrict__ out_keys, u64* __restrict__ out_counts,
                                                        u64* __restrict__ stats) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_count_compact(const u64* __restrict__ t
 }
 
 // ---- k_gate_direct (v0): S bit p = window [p,p+21) valid and its canonical 21-mer has count >= 2 --------
-__global__ void __launch_bounds__(256) k_gate_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(256) k_gate_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                      const u32* __restrict__ endm, u64 n_words,
                                                      const u64* __restrict__ tkeys, const u64* __restrict__ tcounts,
                                                      u64 cap_mask, u32* __restrict__ S) {
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256) k_gate_direct(const u64* __restrict__ fw,
 // ---- k_bloom_direct (v0): pass(p) = window [p,p+k) valid and S[p..p+k-21] all set; insert canonical k-mer
 // stats[0] = valid k windows, stats[1] = passing windows
 template <int NW>
-__global__ void __launch_bounds__(256) k_bloom_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(256) k_bloom_direct(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, const u32* __restrict__ S,
                                                       u64 n_words, u32 k, ModM mm, u32 H, u32* __restrict__ bloom,
                                                       u32* __restrict__ P, u64* __restrict__ stats) {
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256) k_bloom_direct(const u64* __restrict__ fw
 
 // ---- k_seeds: first set bit of P inside each admitted read -> forward key of that window --------------
 template <int NW>
-__global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, u64 n_reads, u32 min_len, u32 k,
+static __global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, u64 n_reads, u32 min_len, u32 k,
                                                const u32* __restrict__ P, const u64* __restrict__ fw,
                                                u64* __restrict__ seed_keys, uint8_t* __restrict__ seed_valid,
                                                u64* __restrict__ n_seed_reads) {
@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(256) k_seeds(const u64* __restrict__ offsets, 
 
 // ---- k_bloom_query: B2 -----------------------------------------------------------------------------------
 template <int NW>
-__global__ void __launch_bounds__(256) k_bloom_query(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
+static __global__ void __launch_bounds__(256) k_bloom_query(const u64* __restrict__ keys, u64 n, u32 k, ModM mm, u32 H,
                                                      const u32* __restrict__ bloom, uint8_t* __restrict__ out) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

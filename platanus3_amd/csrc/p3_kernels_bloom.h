@@ -297,7 +297,7 @@ struct PassWords {
 // ---- k_kmer_hist ---------------------------------------------------------------------------------------------
 // stats[0] += valid k windows, stats[1] += passing windows
 template <int NW>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                const u32* __restrict__ endm, const u32* __restrict__ S,
                                                                u64 n_words, u32 k, u32* __restrict__ ghist,
                                                                u32* __restrict__ P, u64* __restrict__ stats) {
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_hist(const u64* __rest
 // FROM_S = false: the pass bitmap P was produced by k_kmer_hist (exact mode).  FROM_S = true (estimated mode, no
 // histogram pass): the windowed AND of S is evaluated here, P is written and the two statistics are accumulated.
 template <int NW, bool FROM_S>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                   const u32* __restrict__ endm, u32* __restrict__ P,
                                                                   const u32* __restrict__ S, u64 n_words, u32 k,
                                                                   const u32* __restrict__ seg_off,
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u64* __r
 // ---- k_kmer_dedup ---------------------------------------------------------------------------------------------
 // gstats[0] = distinct cursor, gstats[3] = overflow flag.  LDS: NW==1: u64 slots; NW==2: state + lo + hi.
 template <int NW>
-__global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::type* __restrict__ part,
+static __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off, const u32* __restrict__ ghist,
                                                      u32 sbits, u32 ts_log2, u64* __restrict__ out_keys,
                                                      u64* __restrict__ gstats, u32 dbg) {
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<NW>::ty
 
 // ---- k_bloom_insert: H probes per distinct key, global atomicOr -------------------------------------------------
 template <int NW>
-__global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, const u64* __restrict__ n_ptr, u32 k,
+static __global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, const u64* __restrict__ n_ptr, u32 k,
                                                       ModM mm, u32 H, u32* __restrict__ bloom) {
   const u64 n = *n_ptr;
   const u64 stride = (u64)gridDim.x * blockDim.x;
@@ -655,7 +655,7 @@ __device__ __forceinline__ void pos_key_range(u64 n, u32 wg, u64& begin, u64& en
 }
 
 template <int NW>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                               u32 k, ModM mm, u32 H, u32 slice_log2,
                                                               u32* __restrict__ ghist) {
   const u64 n = *n_ptr;  // number of distinct keys, left on the device by k_kmer_dedup
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_hist(const u64* __restr
 //    workgroup) and strip j is walked from a start rotated by j/256 of its length, which also separates the strips
 //    that sit at the same offset of different chunks.
 template <int NW>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u64* __restrict__ keys, u64 n,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u64* __restrict__ keys, u64 n,
                                                                  typename KRec<NW>::type* __restrict__ part, EstSeg est) {
   typedef typename KRec<NW>::type REC;
   constexpr int RW = (NW == 1) ? 4 : 2;
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u64* __r
 template <int NW, bool MULTI>  // MULTI: one of several sweeps over a vector of more than 1024 slices
 // totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
 // raises *cap_flag and writes nothing (the host re-runs with a larger buffer).
-__global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                                  u32 k, ModM mm, u32 H, u32 slice_log2,
                                                                  const u32* __restrict__ seg_off, u32* __restrict__ out,
                                                                  const u64* __restrict__ totals, u64 cap,
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __re
 
 // one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else
 // writes it in this mode).  n_u32 = number of u32 words of the whole vector.
-__global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+static __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
                                                        u32* __restrict__ bloom, const u64* __restrict__ cap_flag,
                                                        u32 accumulate, u32 slice_base) {

@@ -184,7 +184,7 @@ __device__ __forceinline__ bool node_insert(const DbgTab& t, u64 clo, u64 chi, u
 // ---- k_dbg_expand ------------------------------------------------------------------------------------------------
 // ctr[0] = next-frontier cursor, ctr[1] = nodes inserted so far, ctr[2] = overflow flag (table too full / frontier full)
 template <int NW>
-__global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict__ fin, const uint8_t* __restrict__ fin_valid,
+static __global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict__ fin, const uint8_t* __restrict__ fin_valid,
                                                     u64 n_in, u64* __restrict__ fout, u64 fout_cap, DbgTab t,
                                                     const u32* __restrict__ bloom, DbgParams p, u64 node_limit,
                                                     u64* __restrict__ ctr) {
@@ -251,7 +251,7 @@ __device__ __forceinline__ bool is11(u32 info) { return __popc(info & 15) == 1 &
 // ---- k_dbg_classify: junction flags and run-end flags -------------------------------------------------------------
 // ctr[3] = junction id cursor
 template <int NW>
-__global__ void __launch_bounds__(256) k_dbg_classify(DbgTab t, DbgParams p, u64* __restrict__ ctr) {
+static __global__ void __launch_bounds__(256) k_dbg_classify(DbgTab t, DbgParams p, u64* __restrict__ ctr) {
   const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (s > t.cap_mask) return;
   const u32 info = t.info[s];
@@ -287,7 +287,7 @@ struct DbgRun {
 };
 
 template <int NW, int PASS>
-__global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, DbgRun* __restrict__ runs,
+static __global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, DbgRun* __restrict__ runs,
                                                   const u64* __restrict__ seq_off, char* __restrict__ seq,
                                                   u64 n_runs, u64* __restrict__ ctr, u64 max_steps) {
   const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, DbgRun*
 
 // junction keys by id (for the export / GFA writer)
 template <int NW>
-__global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __restrict__ jkeys) {
+static __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __restrict__ jkeys) {
   const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (s > t.cap_mask) return;
   if (!(t.info[s] & DBG_JUNCTION)) return;
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __restrict__ 
 // jtcov[2 * straight + 0 / 1] = JointInfo::coverage of the straight's left / right joint (:445-447: a window counts once
 // for the joint it equals in either orientation, twice when it is its own reverse complement)
 template <int NW>
-__global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, const uint8_t* __restrict__ bases,
                                                       u64 n_bases, u64 n_words, DbgTab t, DbgParams p,
                                                       u32* __restrict__ jcov, u32* __restrict__ jtcov) {
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw
 // ---- k_dbg_edges: PrintGraph's L lines (:468-543) as records -------------------------------------------------------
 // rec = {A, B}: bit 31 = 1 straight / 0 junction, bit 30 = 1 '-' / 0 '+', low bits = id (0-based)
 template <int NW>
-__global__ void __launch_bounds__(256) k_dbg_edges(DbgTab t, DbgParams p, const u32* __restrict__ bloom,
+static __global__ void __launch_bounds__(256) k_dbg_edges(DbgTab t, DbgParams p, const u32* __restrict__ bloom,
                                                    const u32* __restrict__ jcov, uint2* __restrict__ edges, u64 edge_cap,
                                                    u64* __restrict__ ctr) {
   const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void part_word_range(u64 n_words, u32 wg, u64& begin,
 
 // ---- k_part_hist -------------------------------------------------------------------------------------
 // ghist[pb * P3_NWG + wg] = number of records workgroup wg will send to bucket pb
-__global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                const u32* __restrict__ endm, u64 n_words,
                                                                u32* __restrict__ ghist) {
   __shared__ u32 hist[P3_NB];
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_hist(const u64* __rest
 // Three small launches instead of one single-workgroup kernel (which spent ~80 us walking 1024 rows with one
 // load in flight per wave):  a) per-row wave scan on 64 workgroups, b) scan of the 1024 row totals,
 // c) add the bucket base.
-__global__ void __launch_bounds__(256) k_part_scan_rows(const u32* __restrict__ ghist, u32* __restrict__ seg_off,
+static __global__ void __launch_bounds__(256) k_part_scan_rows(const u32* __restrict__ ghist, u32* __restrict__ seg_off,
                                                         u32* __restrict__ bucket_count, u32* __restrict__ padded) {
   static_assert(P3_NWG == 256, "one wave scans one 256-entry row with 4 entries per lane");
   const u32 lane = threadIdx.x & 63;
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_part_scan_rows(const u32* __restrict__ 
 }
 
 // totals[0] = valid records, totals[1] = padded records, totals[2] = largest bucket; padded[] becomes base[]
-__global__ void __launch_bounds__(P3_NB) k_part_scan_base(u32* __restrict__ padded, const u32* __restrict__ bucket_count,
+static __global__ void __launch_bounds__(P3_NB) k_part_scan_base(u32* __restrict__ padded, const u32* __restrict__ bucket_count,
                                                           u64* __restrict__ totals) {
   __shared__ u32 buf[P3_NB];
   const u32 t = threadIdx.x, lane = t & 63;
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(P3_NB) k_part_scan_base(u32* __restrict__ padd
   }
 }
 
-__global__ void __launch_bounds__(256) k_part_scan_add(u32* __restrict__ seg_off, const u32* __restrict__ base) {
+static __global__ void __launch_bounds__(256) k_part_scan_add(u32* __restrict__ seg_off, const u32* __restrict__ base) {
   const u32 lane = threadIdx.x & 63;
   const u32 pb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pb >= P3_NB) return;
@@ -211,7 +211,7 @@ __device__ __forceinline__ void part_flush(u32* stage, u32* cnt, u32* wpos, cons
   }
 }
 
-__global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                   const u32* __restrict__ endm, u64 n_words,
                                                                   const u32* __restrict__ seg_off,
                                                                   u32* __restrict__ part) {
@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u64* __r
 // TAGGED (POS only): a re-partitioned multi-source cell is read in one sweep with per-segment source tags; it is a
 // template parameter so that the single-source kernel does not carry that code.
 template <bool POS, bool TAGGED = false>
-__global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
+static __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off,
                                                      const u32* __restrict__ ghist, const u64* __restrict__ roff,
                                                      u32 n_src, u32 rows, u32 first_pb, u32 xbits, u32 sbits,
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditi
 }
 
 // ---- k_solid_regions: region[sb] = open-addressing table (rs slots) of the solid remainders of sub-bucket sb
-__global__ void __launch_bounds__(256) k_solid_regions(const u64* __restrict__ keys, const u32* __restrict__ counts,
+static __global__ void __launch_bounds__(256) k_solid_regions(const u64* __restrict__ keys, const u32* __restrict__ counts,
                                                        const uint4* __restrict__ sb_info, u32 first_sb, u32 sbits,
                                                        u32 rs_log2, u32* __restrict__ solid) {
   extern __shared__ __align__(16) u32 lds[];
@@ -657,7 +657,7 @@ __device__ __forceinline__ bool solid_lookup(const u32* __restrict__ solid, u32 
 // ---- k_gate_regions ---------------------------------------------------------------------------------------
 // One probe chain per window.  (A variant that issued 16 probes per lane per round measured 25 % SLOWER: the
 // kernel is bound by Infinity-Cache line traffic of the random table reads, not by their latency.)
-__global__ void __launch_bounds__(256) k_gate_regions(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(256) k_gate_regions(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, u64 n_words,
                                                       const u32* __restrict__ solid, u32 sbits, u32 rs_log2,
                                                       u32* __restrict__ S) {

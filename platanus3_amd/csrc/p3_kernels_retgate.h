@@ -16,13 +16,13 @@
 #include "p3_kernels_bloom.h"
 
 // seg_off for the readers in estimated mode: fixed stride, no histogram / scan
-__global__ void __launch_bounds__(256) k_fixed_segoff(u32* __restrict__ seg_off, u32 segcap) {
+static __global__ void __launch_bounds__(256) k_fixed_segoff(u32* __restrict__ seg_off, u32 segcap) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < P3_NB * P3_NWG) seg_off[i] = i * segcap;
 }
 
 // ---- k_part_scatter_pos: as k_part_scatter, records = (position << 32) | low 32 bits of g -----------------------
-__global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                       const u32* __restrict__ endm, u64 n_words,
                                                                       const u32* __restrict__ seg_off,
                                                                       u64* __restrict__ part, EstSeg est) {
@@ -86,7 +86,7 @@ __device__ __forceinline__ void u32_range(u64 n, u32 wg, u64& begin, u64& end) {
 }
 
 // (the element count is read from device memory so that the host need not synchronise to learn it)
-__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
                                                               u32 shift, u32* __restrict__ ghist) {
   const u64 n = *n_ptr;
   __shared__ u32 hist[P3_NB];
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_hist(const u32* __restr
   for (u32 i = threadIdx.x; i < P3_NB; i += blockDim.x) ghist[i * P3_NWG + blockIdx.x] = hist[i];
 }
 
-__global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __restrict__ vals, const u64* __restrict__ n_ptr,
                                                                  u32 shift, const u32* __restrict__ seg_off,
                                                                  u32* __restrict__ out, EstSeg est) {
   const u64 n = *n_ptr;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_u32_scatter(const u32* __re
 
 // ---- k_solid_slices: S[w] = valid21 bits of word w AND NOT the non-solid bits of this slice --------------------------
 // valid21 bit j of word w <=> no read-end mark in positions [32w+j, 32w+j+20)
-__global__ void __launch_bounds__(1024) k_solid_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+static __global__ void __launch_bounds__(1024) k_solid_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2,
                                                        const u32* __restrict__ endm, u64 n_words, u32* __restrict__ S) {
   extern __shared__ __align__(16) u32 lds[];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(1024) k_solid_slices(const u32* __restrict__ p
 // (source, bucket) pairs 4w..4w+3 -- all from ONE source because 1024/N is a multiple of 4 -- so segment w of
 // every cell is single-source, which is how the count kernel still knows whose read a position indexes.
 template <typename REC>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_repart_hist(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_hist(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
                                                                  const u32* __restrict__ rx_ghist,
                                                                  const u64* __restrict__ roff, u32 rows, u32 xbits,
                                                                  u32* __restrict__ ghist) {
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_hist(const REC* __re
 // ranks its records per cell with ballots and writes each cell's run contiguously at an LDS-held cursor
 // (exact offsets from k_repart_hist + scan, so no global atomics either).
 template <typename REC>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* __restrict__ rx, const u32* __restrict__ rx_segoff,
                                                                     const u32* __restrict__ rx_ghist,
                                                                     const u64* __restrict__ roff, u32 rows, u32 xbits,
                                                                     const u32* __restrict__ seg_off, REC* __restrict__ out) {
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_repart_scatter(const REC* _
 }
 
 // sum of a u32 array into *out (valid-window total when no histogram scan produced it)
-__global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 n, u64* __restrict__ out) {
+static __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 n, u64* __restrict__ out) {
   __shared__ unsigned long long blk;
   if (threadIdx.x == 0) blk = 0;
   __syncthreads();
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ v, u32 
 // segment index (k_split, k_repart_*) then see a balanced partition, as from the level-1 scatter.
 __device__ __forceinline__ u32 agg_slice(u32 n, u32 per) { return (((n + per - 1) / per) + 15u) & ~15u; }
 
-__global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
+static __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P3_NB * P3_NWG) return;
   const u32 pb = i / P3_NWG, j = i % P3_NWG;
@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_i
   ghist[i] = done >= n ? 0u : (n - done < slice ? n - done : slice);
 }
 
-__global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
+static __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
                                                      const u32* __restrict__ seg_off, u32 sbits, u32 ts_log2,
                                                      u64* __restrict__ out) {
   const u32 sb = blockIdx.x;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pai
 // KIND 1 / 2: canonical k-mer records of the Bloom stage (u64 / Rec16): the cell bits are the xbits bits below the
 // bucket bits of the k-mer's bucket hash (kfold * C1), i.e. the bits a sub-bucket split of the dedup stage would use.
 template <typename REC, int KIND>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
                                                           const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
                                                           u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
                                                           REC* __restrict__ out, EstSeg est,
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __restrict
 // into a capacity per cell -- the uniform one, or what the sample predicts for the cell plus its 6 sigma -- lays the
 // segments out and leaves the table of capacities for the stager (EstSeg::caps).  Nothing is read back by the host.
 template <typename REC, int KIND>
-__global__ void __launch_bounds__(P3_PART_THREADS) k_cell_sample(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_cell_sample(const REC* __restrict__ in, const u32* __restrict__ in_segoff,
                                                                 const u32* __restrict__ in_ghist, const u64* __restrict__ roff,
                                                                 u32 n_src, u32 desc_rows, u32 first_row, u32 rows, u32 xbits,
                                                                 u32* __restrict__ cellcnt) {
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_cell_sample(const REC* __re
 // one workgroup of P3_NB threads.  seg_scale = 64 (sampling) x margin / P3_NWG: sampled records of a cell -> expected
 // records of one of its segments; boost_mul = extra factor on that (1: the sample already sees the skew); cap_records = records the output
 // buffer holds (*flag is raised when the capacities do not fit it).  cellcnt is left zeroed for the next group.
-__global__ void __launch_bounds__(P3_NB) k_var_caps(u32* __restrict__ cellcnt, float seg_scale, float boost_mul, u32 uniform_cap,
+static __global__ void __launch_bounds__(P3_NB) k_var_caps(u32* __restrict__ cellcnt, float seg_scale, float boost_mul, u32 uniform_cap,
                                                     u64 cap_records, u32* __restrict__ caps, u32* __restrict__ seg_off,
                                                     u64* __restrict__ flag) {
   __shared__ u64 base[P3_NB];

@@ -16,7 +16,7 @@
 #include "p3_device.h"
 
 template <int NW>
-__global__ void __launch_bounds__(1024) k_seed_scatter(const u64* __restrict__ seed_keys, const uint8_t* __restrict__ seed_valid,
+static __global__ void __launch_bounds__(1024) k_seed_scatter(const u64* __restrict__ seed_keys, const uint8_t* __restrict__ seed_valid,
                                                        u64 n_reads, u32 k, u32 bbits, u32 segcap, u64* __restrict__ part,
                                                        u32* __restrict__ ghist, u32* __restrict__ flag) {
   extern __shared__ __align__(16) u32 lds[];
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(1024) k_seed_scatter(const u64* __restrict__ s
 
 // LDS: keys lo[N] (+ hi[N] for NW == 2), N = lds_keys (power of two)
 template <int NW>
-__global__ void __launch_bounds__(1024) k_seed_sort(const u64* __restrict__ part, const u32* __restrict__ ghist, u32 nseg,
+static __global__ void __launch_bounds__(1024) k_seed_sort(const u64* __restrict__ part, const u32* __restrict__ ghist, u32 nseg,
                                                     u32 segcap, u32 lds_keys, u32 ocap, u64* __restrict__ out,
                                                     u32* __restrict__ ucount, u32* __restrict__ flag) {
   extern __shared__ __align__(16) u32 lds[];

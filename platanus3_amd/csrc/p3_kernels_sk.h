@@ -78,7 +78,7 @@ struct SkSeg {
 // word boundary.  The record is written where the run ENDS (static j): lo = the 32 bases that end with the run's last
 // base (the run's first window starts 2 (len - 1) bits further up), hi = start position | (len - 1) << 32 | sub << 40.
 // stats[0] += valid windows.
-__global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                   const u32* __restrict__ endm, u64 n_words,
                                                                   uint4* __restrict__ part, SkSeg seg, u32 fbits,
                                                                   u64* __restrict__ stats) {
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_scatter21(const u64* __r
 #define SK_QCAP 128u
 #define SK_TASKS 768u  // tasks of one round: 64 records x <= 12 windows
 #define SK_WAVE_LDS (64u * 24u + (SK_TASKS + 64u) * 2u + SK_QCAP * 12u)
-__global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
+static __global__ void __launch_bounds__(1024) k_sk_count(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
                                                    u32 fbits, u32 xbits, u32 ts_log2, u64* __restrict__ out_keys,
                                                    u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                    u64* __restrict__ gstats, u64* __restrict__ tpairs,
@@ -494,7 +494,7 @@ __device__ __forceinline__ void sk_combine(const u32 (&A)[32 + 15], u32 (&sig)[3
   for (int j = 0; j < 32; j++) sig[j] = A[j] < A[j + D] ? A[j] : A[j + D];
 }
 
-__global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
+static __global__ void __launch_bounds__(P3_PART_THREADS) k_sk_kscatter(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                  const u32* __restrict__ endm, u32* __restrict__ P,
                                                                  const u32* __restrict__ S, u64 n_words, u32 k,
                                                                  uint4* __restrict__ part, SkSeg seg, u32 fbits,
@@ -624,7 +624,7 @@ __device__ __forceinline__ u64 sk_shr128(u64 lo, u64 hi, u32 s) {  // bits [s, s
   const u64 a = s < 64u ? lo : hi, b = s < 64u ? hi : 0ULL;
   return sh ? ((a >> sh) | (b << (64u - sh))) : a;
 }
-__global__ void __launch_bounds__(1024) k_sk_dedup(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
+static __global__ void __launch_bounds__(1024) k_sk_dedup(const uint4* __restrict__ part, const u32* __restrict__ ghist, u32 segcap,
                                                    u32 fbits, u32 xbits, u32 ts_log2, u32 k, u64* __restrict__ out_keys,
                                                    u64* __restrict__ gstats) {
   extern __shared__ __align__(16) u32 lds[];
