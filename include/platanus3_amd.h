@@ -253,6 +253,37 @@ int p3_mr_or_reduce(p3_ctx* ctx, void* d_dst, const void* d_src, uint64_t n_word
                     uint64_t stride_words);
 int p3_mr_alloc_scratch(p3_ctx* ctx, uint64_t bytes, void** d_ptr);
 
+/* ---- the exchange inside the library ("owns streams, RCCL communicator"; section 8e) -----------
+ * p3_mr_run_pass runs the whole sharded pass of one rank -- the p3_mr_* steps above and the exchanges between them -- on the
+ * context's stream, through a communicator the library owns:
+ *   p3_comm_create_rccl       RCCL over xGMI (librccl is opened at run time): rank 0 makes an id with p3_comm_unique_id,
+ *                             the host program hands it to every rank (any channel: MPI, a file, torch.distributed, or
+ *                             plain memory for the threads of one process), every rank creates its communicator
+ *   p3_comm_create_callbacks  the caller moves the bytes (tests: N contexts on one GPU; other transports)
+ * All buffers are DEVICE pointers.  all_to_all_v: for every peer s, `send_counts[s]` elements of `elem_bytes` starting at
+ * element `send_offsets[s]` of d_send go to s, and `recv_counts[s]` elements from s land at element `recv_offsets[s]` of
+ * d_recv.  all_gather: `bytes` from every rank, in rank order.  all_reduce_u64: n host values, op 0 = max, 1 = sum.
+ * A callback returns 0 on success. */
+typedef struct p3_comm p3_comm;
+typedef struct {
+  void* user;
+  int (*all_to_all_v)(void* user, const void* d_send, const uint64_t* send_offsets, const uint64_t* send_counts, void* d_recv,
+                      const uint64_t* recv_offsets, const uint64_t* recv_counts, uint32_t elem_bytes, void* hip_stream);
+  int (*all_gather)(void* user, const void* d_send, void* d_recv, uint64_t bytes, void* hip_stream);
+  int (*all_reduce_u64)(void* user, uint64_t* values, uint32_t n, int op);
+} p3_comm_callbacks;
+#define P3_COMM_ID_BYTES 128
+int p3_comm_unique_id(uint8_t id[P3_COMM_ID_BYTES]);
+int p3_comm_create_rccl(p3_comm** out, const uint8_t id[P3_COMM_ID_BYTES], uint32_t rank, uint32_t n_ranks, int device_ordinal);
+int p3_comm_create_callbacks(p3_comm** out, const p3_comm_callbacks* cb, uint32_t rank, uint32_t n_ranks);
+int p3_comm_destroy(p3_comm* comm);
+const char* p3_comm_last_error(const p3_comm* comm);
+/* One rank's share of the pass: count (partition, all-to-all to the bucket owners, owners count), gate (non-solid
+ * positions back to the ranks whose reads they index, or all-gather of the solid regions), Bloom (rank-local partial
+ * vector, OR-merge: all-to-all of word chunks + all-gather).  Calls p3_mr_config(ctx, rank, n_ranks of comm) itself.
+ * Afterwards the count table is sharded by bucket owner and every rank holds the whole Bloom vector. */
+int p3_mr_run_pass(p3_ctx* ctx, p3_comm* comm, uint32_t k, uint64_t m_bits, uint32_t H);
+
 /* ---- synthetic workload (plain C, CPU) -------------------------------------- */
 uint64_t p3_synth_genome_length(uint64_t total_reads, uint32_t read_len, uint32_t coverage);
 int p3_synth_reads(uint64_t seed, uint64_t total_reads, uint64_t first_read, uint64_t n_reads,

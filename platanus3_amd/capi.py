@@ -95,6 +95,13 @@ def load(build=False):
     L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]
     L.p3_export_edges.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
     L.p3_export_joints.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.p3_comm_unique_id.argtypes = [vp]
+    L.p3_comm_create_rccl.argtypes = [C.POINTER(vp), vp, C.c_uint32, C.c_uint32, C.c_int]
+    L.p3_comm_create_callbacks.argtypes = [C.POINTER(vp), vp, C.c_uint32, C.c_uint32]
+    L.p3_comm_destroy.argtypes = [vp]
+    L.p3_comm_last_error.argtypes = [vp]
+    L.p3_comm_last_error.restype = C.c_char_p
+    L.p3_mr_run_pass.argtypes = [vp, vp, C.c_uint32, u64, C.c_uint32]
     L.p3_write_gfa.argtypes = [vp, C.c_char_p]
     L.p3_mr_config.argtypes = [vp, u32, u32]
     L.p3_mr_count_partition.argtypes = [vp]
@@ -283,6 +290,11 @@ class Context:
                 out.append((min(kmer, rc), int(c)))
         return sorted(out)
 
+    def mr_run_pass(self, comm, k, m, H):
+        """one rank's share of the sharded pass with the exchanges INSIDE the library (p3_exchange.hip)"""
+        self._chk(self.L.p3_mr_run_pass(self.h, comm.h, k, m, H))
+        self.k, self.m, self.H = k, m, H
+
     # ---- multi-rank protocol (device pointers are returned as plain ints) ----------------------------
     def mr_config(self, rank, n_ranks):
         self._chk(self.L.p3_mr_config(self.h, rank, n_ranks))
@@ -380,3 +392,62 @@ def decode_key(words, k):
     for i, w in enumerate(words):
         v |= int(w) << (64 * i)
     return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+# ---- communicators of the in-library exchange ---------------------------------------------------------------------------
+A2AV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p)
+AG_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+AR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_int)
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all_v", A2AV_FN), ("all_gather", AG_FN), ("all_reduce_u64", AR_FN)]
+
+
+def comm_unique_id():
+    """rank 0: the id every rank needs for Comm.rccl (hand it over by any channel)"""
+    buf = (C.c_uint8 * 128)()
+    rc = load().p3_comm_unique_id(buf)
+    if rc != 0:
+        raise P3Error(rc, "p3_comm_unique_id (librccl not loadable?)")
+    return bytes(buf)
+
+
+class Comm:
+    """p3_comm: RCCL (Comm.rccl) or caller callbacks (Comm.callbacks: the three functions get DEVICE pointers)"""
+
+    def __init__(self, h, keep=None):
+        self.h, self._keep = h, keep
+
+    @classmethod
+    def rccl(cls, unique_id, rank, n_ranks, device):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = load().p3_comm_create_rccl(C.byref(h), buf, rank, n_ranks, device)
+        if rc != 0:
+            raise P3Error(rc, "p3_comm_create_rccl")
+        return cls(h)
+
+    @classmethod
+    def callbacks(cls, rank, n_ranks, all_to_all_v, all_gather, all_reduce_u64):
+        def guard(fn):
+            def run(*a):
+                try:
+                    return int(fn(*a[1:]) or 0)
+                except Exception:  # noqa: BLE001  (an exception must not cross the C frames)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return run
+        cb = CommCallbacks(None, A2AV_FN(guard(all_to_all_v)), AG_FN(guard(all_gather)), AR_FN(guard(all_reduce_u64)))
+        h = C.c_void_p()
+        rc = load().p3_comm_create_callbacks(C.byref(h), C.byref(cb), rank, n_ranks)
+        if rc != 0:
+            raise P3Error(rc, "p3_comm_create_callbacks")
+        return cls(h, keep=cb)
+
+    def close(self):
+        if self.h:
+            load().p3_comm_destroy(self.h)
+            self.h = None

@@ -223,7 +223,9 @@ int p3_destroy(p3_ctx* c) {
                     &c->or_tmp, &c->scan_tmp, &c->part8, &c->tpos, &c->tsrc, &c->singles, &c->sing_cursor, &c->ns_recv,
                     &c->ns_part, &c->lpart, &c->g_klo, &c->g_khi, &c->g_info, &c->g_nid, &c->g_f0, &c->g_f1, &c->g_ctr,
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
-                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps};
+                    &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps, &c->unk_flag,
+                    &c->seed_part, &c->seed_hist, &c->seed_set, &c->seed_ucount, &c->seed_flag, &c->g_jtcov, &c->xc_buf,
+                    &c->xg_buf};
   for (DevBuf* b : bufs) release(*b);
   free_outgrown(c);
   for (auto& ev : c->ev)

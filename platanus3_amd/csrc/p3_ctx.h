@@ -6,7 +6,7 @@
 //   p3_count.hip   C1: the count stage's drivers (direct table, partitioned, second-level groups, position chunks,
 //                  multi-rank owner side, run records) and its entry points
 //   p3_bloom.hip   G1/G2/B1/B2: gate, k-mer partition + dedup, probes, LDS slices, seeds, the seed set; p3_run_pass
-//   p3_mr.hip      the p3_mr_* protocol steps and the in-library exchange (p3_mr_run_pass)
+//   p3_mr.hip      the p3_mr_* protocol steps; p3_exchange.hip: communicators (RCCL / callbacks) and p3_mr_run_pass
 //   p3_graph.hip   G3-G6: de Bruijn stage and its exports
 // Functions used across units live in namespace p3i and are declared here.  Kernel headers are included by every unit
 // that launches from them (their kernels have internal linkage).
@@ -92,6 +92,7 @@ struct p3_ctx {
   DevBuf kpart, dkeys, ppart, scan_tmp;
   // multi-rank protocol state (n_ranks = 1: the rx_* pointers alias the local partition)
   u32 rank = 0, n_ranks = 1;
+  DevBuf xc_buf, xg_buf;  // p3_mr_run_pass: count staging, gathered chunk
   DevBuf rx_roff, rx_part_buf, rx_ghist_buf, rx_segoff_buf, or_tmp;
   void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
   u64 rx_records = 0;

@@ -11,6 +11,8 @@ backend).  Exchanges:
   gate    all-gather of the owners' solid-key regions (every rank then gates its own reads locally)
   Bloom   OR-merge of the ranks' partial bit vectors: all-to-all of word chunks, local OR, all-gather
 """
+import os
+
 import numpy as np
 
 from . import capi
@@ -188,6 +190,26 @@ class Pipeline:
         if self.protocol:
             self.be.mr_config(rank, world)
         self.timing = {}
+        # The exchange INSIDE the library (p3_mr_run_pass over the library's own RCCL communicator: no Python, no torch
+        # between the protocol steps) whenever this is a real multi-GPU job; the Python protocol below remains for the
+        # CPU stand-in, the loopback harness, and as the fallback when librccl cannot be opened.  P3_PY_EXCHANGE=1 forces it.
+        self.native = None
+        if (world > 1 and backend is None and comm is None and self.ctx is not None
+                and os.environ.get("P3_PY_EXCHANGE", "0") != "1"):
+            self.native = self._native_comm(device, rank, world, group)
+
+    def _native_comm(self, device, rank, world, group):
+        import torch.distributed as dist
+        try:
+            if dist.get_backend(group) != "nccl":
+                return None
+            obj = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(obj, src=0, group=group)
+            return capi.Comm.rccl(obj[0], rank, world, device)
+        except Exception as e:  # noqa: BLE001
+            import sys
+            print("platanus3_amd: in-library exchange unavailable (%s); using the torch.distributed protocol" % e, file=sys.stderr)
+            return None
 
     def load_reads(self, bases, offsets, min_len):
         self.be.load_reads(bases, offsets, min_len)
@@ -199,6 +221,9 @@ class Pipeline:
     def run_pass(self, k, m, H):
         if not self.protocol:
             self.ctx.run_pass(k, m, H)
+            return
+        if self.native is not None:
+            self.ctx.mr_run_pass(self.native, k, m, H)
             return
         import torch
         be, W, cm = self.be, self.world, self.comm
@@ -282,9 +307,11 @@ class Pipeline:
         self.ctx.set_option("drop_hints", 1)
 
     def parallelism(self):
-        return "reads sharded by index x%d" % self.world
+        return "reads sharded by index x%d%s" % (self.world, ", exchange inside the library (RCCL)" if self.native is not None else "")
 
     def close(self):
+        if self.native is not None:
+            self.native.close()
         self.ctx.close()
 
     @staticmethod

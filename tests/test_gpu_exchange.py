@@ -1,0 +1,169 @@
+"""GPU tier: the exchange INSIDE the library (p3_exchange.hip: p3_comm_* + p3_mr_run_pass, SURVEY.md sections 8b / 8e).
+
+  * one rank over a REAL RCCL communicator (the only world size one GPU allows): librccl opened by the library, id,
+    ncclCommInitRank, grouped send/recv to self, all-gather, all-reduce on the context's stream
+  * 2 / 4 / 8 ranks on one GPU through the callback communicator: N contexts driven by threads, the callbacks copy
+    between the ranks' DEVICE buffers -- the same p3_mr_run_pass code path as over RCCL, minus the wire
+Results must equal the single-rank oracle on the union of the reads, bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import platanus3_amd.synth as synth
+from platanus3_amd import capi
+from platanus3_amd.pipeline import _DevMem
+
+pytestmark = pytest.mark.gpu
+
+
+def _bytes(ptr, n):
+    if n == 0:
+        return torch.empty(0, dtype=torch.uint8, device="cuda:0")
+    return torch.as_tensor(_DevMem(ptr, n), device="cuda:0")
+
+
+class PtrWorld:
+    """rendezvous of N rank threads; the callbacks get raw device pointers"""
+
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slot = [None] * n
+
+    def callbacks(self, rank):
+        w, n = self, self.n
+
+        def a2av(d_send, soff, scnt, d_recv, roff, rcnt, elem, stream):
+            torch.cuda.synchronize()
+            w.slot[rank] = (d_send, [soff[i] for i in range(n)], [scnt[i] for i in range(n)])
+            w.barrier.wait()
+            for s in range(n):
+                ptr, so, sc = w.slot[s]
+                nb = sc[rank] * elem
+                assert sc[rank] == rcnt[s], (rank, s, sc[rank], rcnt[s])
+                if nb:
+                    _bytes(d_recv + roff[s] * elem, nb).copy_(_bytes(ptr + so[rank] * elem, nb))
+            torch.cuda.synchronize()
+            w.barrier.wait()
+            return 0
+
+        def allgather(d_send, d_recv, nbytes, stream):
+            torch.cuda.synchronize()
+            w.slot[rank] = d_send
+            w.barrier.wait()
+            for s in range(n):
+                if nbytes:
+                    _bytes(d_recv + s * nbytes, nbytes).copy_(_bytes(w.slot[s], nbytes))
+            torch.cuda.synchronize()
+            w.barrier.wait()
+            return 0
+
+        def allreduce(values, nv, op):
+            w.slot[rank] = [values[i] for i in range(nv)]
+            w.barrier.wait()
+            cols = list(zip(*w.slot))
+            res = [max(c) if op == 0 else sum(c) for c in cols]
+            w.barrier.wait()
+            for i in range(nv):
+                values[i] = res[i]
+            return 0
+
+        return a2av, allgather, allreduce
+
+
+def _check_union(oracle, b, o, k, m, H, results):
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    keys = np.concatenate([r[0] for r in results])
+    counts = np.concatenate([r[1] for r in results])
+    assert np.unique(keys).size == keys.size, "a key is owned by two ranks"
+    order = np.argsort(keys)
+    assert np.array_equal(keys[order], ekeys) and np.array_equal(counts[order], ecounts)
+    for r in results:
+        assert np.array_equal(r[2], ebloom)
+    assert sorted(set(s for r in results for s in r[3])) == eseeds
+
+
+@pytest.mark.parametrize("gate", [2, 1])
+def test_run_pass_over_rccl_one_rank(oracle, gate):
+    b, o = synth.reads(seed=61, total_reads=20000, read_len=150)
+    k = 31
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    comm = capi.Comm.rccl(capi.comm_unique_id(), 0, 1, 0)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_option("gate_mode", gate)
+        ctx.load_reads(b, o, min_len=k)
+        ctx.mr_run_pass(comm, k, m, H)
+        ctx.mr_run_pass(comm, k, m, H)
+        keys, counts = ctx.export_counts()
+        res = [(keys, counts, ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])]
+        _check_union(oracle, b, o, k, m, H, res)
+    finally:
+        ctx.close()
+        comm.close()
+
+
+@pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 27, 2, 2), (4, 41, 1, 0), (8, 31, 2, 1)])
+def test_run_pass_through_callbacks(oracle, world, k, gate, agg):
+    n_reads = 24000
+    per = n_reads // world
+    b, o = synth.reads(seed=62, total_reads=n_reads, read_len=150)
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    pw = PtrWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            comm = capi.Comm.callbacks(r, world, *pw.callbacks(r))
+            ctx = capi.Context(0)
+            ctx.set_option("gate_mode", gate)
+            ctx.set_option("mr_aggregate", 2 if (agg == 1 or (agg == 2 and r % 2 == 0)) else 0)
+            bb = b[int(o[r * per]):int(o[(r + 1) * per])]
+            oo = o[r * per:(r + 1) * per + 1] - o[r * per]
+            ctx.load_reads(bb, oo, min_len=k)
+            ctx.mr_run_pass(comm, k, m, H)
+            keys, counts = ctx.export_counts()
+            results[r] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            pw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    _check_union(oracle, b, o, k, m, H, results)
+
+
+def test_cpp_host_drives_the_sharded_pass(tmp_path):
+    """platanus3_amd/host/mr_demo.cpp: a C++ program -- one thread per GPU, the library's own RCCL communicators,
+    p3_mr_run_pass -- with no Python in the loop (one GPU here; its numbers must equal the single-rank pass)."""
+    import os
+    import subprocess
+    from platanus3_amd import _build
+    from bench import bloom_sizing
+    host = os.path.join(os.path.dirname(_build.CSRC), "host")
+    exe = os.path.join(str(tmp_path), "mr_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + _build.INCLUDE, os.path.join(host, "mr_demo.cpp"), "-o", exe,
+                           "-L" + _build.CSRC, "-lplatanus3_amd", "-Wl,-rpath," + _build.CSRC, "-pthread"])
+    n, k = 30000, 31
+    out = subprocess.check_output([exe, "1", str(n), str(k)], timeout=120).decode()
+    last = out.strip().split("\n")[-1].split()
+    total, passing = int(last[1]), int(last[4])
+    b, o = synth.reads(seed=3, total_reads=n, read_len=150)
+    m, H = bloom_sizing(int(b.size), k)
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(b, o, min_len=k)
+        ctx.run_pass(k, m, H)
+        assert ctx.count_stats()["n_distinct"] == total
+        assert ctx.bloom_stats()["n_passing"] == passing
+    finally:
+        ctx.close()
