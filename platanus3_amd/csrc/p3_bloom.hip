@@ -13,7 +13,7 @@ int seeds_to_set(p3_ctx* c, u32 k) {
   c->seedset_ready = false;
   if (c->n_reads == 0) return P3_OK;
   u32 bbits = 2;
-  while (bbits < 14 && (c->n_reads >> bbits) > 1024) bbits++;  // <= ~1 Ki seeds per bucket (50 M reads: 3 Ki)
+  while (bbits < 15 && (c->n_reads >> bbits) > 256) bbits++;  // ~256 seeds per bucket: short LDS sorts (50 M reads: 1.5 Ki)
   if (bbits > 2 * k - 2) bbits = 2 * k - 2;
   u32 nwg = (u32)std::min<u64>(256, std::max<u64>(1, c->n_reads / 8192));
   const double mean = (double)c->n_reads / ((double)(1u << bbits) * nwg);

@@ -3,6 +3,13 @@
 
 using namespace p3i;
 
+// k_part_count<POS = true, TAGGED, SUM>: the instance-sum check (P3_K2_SUMCHECK) is compiled in only where asked for
+#define LAUNCH_K2(TAG, ...)                                                                                    \
+  do {                                                                                                          \
+    if (k2_mode(c) & P3_K2_SUMCHECK) LAUNCH_LDS(c, "k_part_count", (k_part_count<true, TAG, true>), __VA_ARGS__); \
+    else LAUNCH_LDS(c, "k_part_count", (k_part_count<true, TAG, false>), __VA_ARGS__);                          \
+  } while (0)
+
 namespace p3i {
 
 int do_count_direct(p3_ctx* c) {
@@ -330,13 +337,13 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
     if (xbits > 0 && c->n_ranks > 1 && (1u << xbits) >= c->n_ranks) {
-      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)kpart,
+      LAUNCH_K2(true, nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
                  k2_mode(c));
     } else {
-      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)kpart,
+      LAUNCH_K2(false, nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
@@ -451,12 +458,12 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
                (EstSeg{var ? P3_VCAP : segcap, (u32*)c->ghist2.p, st + 26, var ? (const u32*)c->caps.p : nullptr}),
                var ? (const u32*)c->seg_off2.p : nullptr);
     if (n_src > 1) {  // (xbits >= log2 n_src by construction)
-      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, true>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+      LAUNCH_K2(true, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
                  (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
     } else {
-      LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+      LAUNCH_K2(false, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
                  (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));

@@ -298,8 +298,8 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter(const u
 #define P3_VCAP_POS 4096u
 #define P3_WQ_CAP_POS 192u
 // TAGGED (POS only): a re-partitioned multi-source cell is read in one sweep with per-segment source tags; it is a
-// template parameter so that the single-source kernel does not carry that code.
-template <bool POS, bool TAGGED = false>
+// template parameter so that the single-source kernel does not carry that code.  SUM (POS only): P3_K2_SUMCHECK.
+template <bool POS, bool TAGGED = false, bool SUM = false>
 static __global__ void __launch_bounds__(1024) k_part_count(const typename std::conditional<POS, u64, u32>::type* __restrict__ part,
                                                      const u32* __restrict__ seg_off,
                                                      const u32* __restrict__ ghist, const u64* __restrict__ roff,
@@ -320,7 +320,7 @@ static __global__ void __launch_bounds__(1024) k_part_count(const typename std::
   // gstats[32] is raised when this table took in 2^32 instances or more (weights included): only then could one of its
   // u32 counters have wrapped, which the max_count >= 2^31 test of the host (the reference's RMQ truncates through
   // int, src/MakeBloomFilter.cpp:11,18) would not see.  Asked for by the host when that many instances exist at all.
-  const bool sumcheck = POS && (mode & P3_K2_SUMCHECK);
+  constexpr bool sumcheck = POS && SUM;  // (a template parameter: the test sits in the per-record loop)
   u64 wsum = 0;
   auto weight_of = [&](REC item) -> u32 {
     if constexpr (POS) {

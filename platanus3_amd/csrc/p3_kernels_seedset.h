@@ -62,14 +62,24 @@ static __global__ void __launch_bounds__(1024) k_seed_sort(const u64* __restrict
     s_out = 0;
   }
   __syncthreads();
-  // gather: every wave takes segments, one ticket per segment
-  for (u32 s = threadIdx.x >> 6; s < nseg; s += blockDim.x >> 6) {
-    const u32 c = ghist[b * nseg + s];
-    u32 base = 0;
-    if ((threadIdx.x & 63) == 0 && c) base = atomicAdd(&s_n, c);
-    base = __shfl(base, 0, 64);
-    const u64* src = part + (u64)(b * nseg + s) * segcap * NW;
-    for (u32 i = threadIdx.x & 63; i < c; i += 64) {
+  // gather: thread t takes segment t (nseg <= blockDim: the scatter's workgroups); offsets from a block-wide scan of the
+  // segment counts, then every thread copies its few keys -- all segments in flight at once
+  __shared__ u32 wtot[16];
+  const u32 lane0 = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u32 cmine = threadIdx.x < nseg ? ghist[b * nseg + threadIdx.x] : 0u;
+  u32 incl = cmine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const u32 t = __shfl_up(incl, off, 64);
+    if ((int)lane0 >= off) incl += t;
+  }
+  if (lane0 == 63) wtot[wv] = incl;
+  __syncthreads();
+  u32 base = incl - cmine;
+  for (u32 w = 0; w < wv; w++) base += wtot[w];
+  if (threadIdx.x == blockDim.x - 1) s_n = base + cmine;
+  if (threadIdx.x < nseg) {
+    const u64* src = part + (u64)(b * nseg + threadIdx.x) * segcap * NW;
+    for (u32 i = 0; i < cmine; i++) {
       if (base + i < lds_keys) {
         klo[base + i] = src[(u64)i * NW];
         if (NW == 2) khi[base + i] = src[(u64)i * NW + 1];
