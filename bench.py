@@ -181,12 +181,21 @@ def main():
     dom_name = None
     cold = None
     dt_all, nk_all = 0.0, 0
+    untimed_passes = 0
     for k in ks:
         m, H = bloom_sizing(all_bases, k)
         n_k_total = total_reads * (L - k + 1)
         for _ in range(args.warmup):
             pipe.run_pass(k, m, H)
         ctx = pipe.ctx
+        untimed = args.warmup + (1 if (k == ks[0] and ctx is not None) else 0)
+        if world > 1 or ctx is None:
+            # the sharded protocol settles its capacities and split over its first three passes (measured: 334, 151,
+            # 312, then 143 ms per pass with 4 ranks on one GPU): they stay outside the timed region whatever W is
+            for _ in range(max(0, 3 - untimed)):
+                pipe.run_pass(k, m, H)
+                untimed += 1
+        untimed_passes = untimed if k == ks[0] else untimed_passes
         if k == ks[0] and ctx is not None:
             # One extra untimed pass with HIP events around EVERY launch: per-kernel split + which kernel dominates.  (A
             # bracket costs ~10 us of stream time, so the timed steps below bracket only the dominant kernel.)
@@ -280,7 +289,7 @@ def main():
              "(EstimateBloomfilter), count+gate+Bloom+seeds" % (names[config], total_reads, L, per, "/".join(str(x) for x in ks),
                                                                 "/".join(str(x["m"]) for x in per_k), per_k[0]["H"])
         out = {"metric": "k-mers/sec through Bloom+MyHash at k=%d; 1/2/4/8 MI355X + %%HBM roofline" % args.k, "value": value,
-               "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_passes": untimed_passes, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64",
                "data": "synthetic",
                "config": {"workload": wl, "parallelism": pipe_parallelism, "distinct_21mers": D, "solid_21mers": cst["n_solid"],

@@ -278,6 +278,19 @@ int p3_comm_create_rccl(p3_comm** out, const uint8_t id[P3_COMM_ID_BYTES], uint3
 int p3_comm_create_callbacks(p3_comm** out, const p3_comm_callbacks* cb, uint32_t rank, uint32_t n_ranks);
 int p3_comm_destroy(p3_comm* comm);
 const char* p3_comm_last_error(const p3_comm* comm);
+/* n host values reduced over the communicator's ranks (op 0 = max, 1 = sum); every rank calls it */
+int p3_comm_all_reduce_u64(p3_comm* comm, uint64_t* values, uint32_t n, int op);
+/* Several protocol ranks inside ONE process -- n_local contexts on one GPU, one host thread each.  One rank addresses at
+ * most 2^30 window positions (30-bit positions in its records), so a GPU whose shard is larger hosts several ranks,
+ * each with its slice.  `outer` joins the processes (NULL: this process is the whole job; else any p3_comm with one rank
+ * per process, used only by local member 0); member i is rank outer_rank * n_local + i of outer_ranks * n_local.  Every
+ * member's thread calls p3_mr_run_pass (or p3_comm_all_reduce_u64) with its own member communicator; collectives between
+ * local members are device-to-device copies, the part that leaves the process is ONE collective of `outer` over packed
+ * staging buffers.  A member that fails aborts the group: the others return P3_ECOMM instead of waiting. */
+typedef struct p3_group p3_group;
+int p3_group_create(p3_group** out, uint32_t n_local, p3_comm* outer);
+int p3_group_destroy(p3_group* group);
+int p3_comm_create_member(p3_comm** out, p3_group* group, uint32_t local_index);
 /* One rank's share of the pass: count (partition, all-to-all to the bucket owners, owners count), gate (non-solid
  * positions back to the ranks whose reads they index, or all-gather of the solid regions), Bloom (rank-local partial
  * vector, OR-merge: all-to-all of word chunks + all-gather).  Calls p3_mr_config(ctx, rank, n_ranks of comm) itself.

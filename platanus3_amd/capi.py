@@ -99,6 +99,10 @@ def load(build=False):
     L.p3_comm_create_rccl.argtypes = [C.POINTER(vp), vp, C.c_uint32, C.c_uint32, C.c_int]
     L.p3_comm_create_callbacks.argtypes = [C.POINTER(vp), vp, C.c_uint32, C.c_uint32]
     L.p3_comm_destroy.argtypes = [vp]
+    L.p3_comm_all_reduce_u64.argtypes = [vp, C.POINTER(u64), C.c_uint32, C.c_int]
+    L.p3_group_create.argtypes = [C.POINTER(vp), C.c_uint32, vp]
+    L.p3_group_destroy.argtypes = [vp]
+    L.p3_comm_create_member.argtypes = [C.POINTER(vp), vp, C.c_uint32]
     L.p3_comm_last_error.argtypes = [vp]
     L.p3_comm_last_error.restype = C.c_char_p
     L.p3_mr_run_pass.argtypes = [vp, vp, C.c_uint32, u64, C.c_uint32]
@@ -447,7 +451,42 @@ class Comm:
             raise P3Error(rc, "p3_comm_create_callbacks")
         return cls(h, keep=cb)
 
+    @classmethod
+    def member(cls, group, local_index):
+        """rank `local_index` of a Group (several protocol ranks in this process)"""
+        h = C.c_void_p()
+        rc = load().p3_comm_create_member(C.byref(h), group.h, local_index)
+        if rc != 0:
+            raise P3Error(rc, "p3_comm_create_member")
+        return cls(h, keep=group)
+
+    def all_reduce(self, values, op="sum"):
+        """host integers reduced over the ranks (every rank calls it); op: "max" or "sum" """
+        vals = list(values)
+        arr = (C.c_uint64 * len(vals))(*vals)
+        rc = load().p3_comm_all_reduce_u64(self.h, arr, len(vals), 0 if op == "max" else 1)
+        if rc != 0:
+            raise P3Error(rc, "p3_comm_all_reduce_u64: " + load().p3_comm_last_error(self.h).decode())
+        return [int(x) for x in arr]
+
     def close(self):
         if self.h:
             load().p3_comm_destroy(self.h)
+            self.h = None
+
+
+class Group:
+    """p3_group: `n_local` protocol ranks in this process (one context and one thread each); `outer` (a Comm with one rank
+    per process, or None) carries what leaves the process"""
+
+    def __init__(self, n_local, outer=None):
+        self.h = C.c_void_p()
+        self.outer = outer
+        rc = load().p3_group_create(C.byref(self.h), n_local, outer.h if outer is not None else None)
+        if rc != 0:
+            raise P3Error(rc, "p3_group_create")
+
+    def close(self):
+        if self.h:
+            load().p3_group_destroy(self.h)
             self.h = None

@@ -36,6 +36,17 @@ bool lendable(const p3_ctx* c, const DevBuf& b) {
   return &b == &c->kpart || &b == &c->klpart || &b == &c->dkeys || &b == &c->dall || &b == &c->ppart;
 }
 
+// name of a context buffer (P3_TRACE_ALLOC diagnostics)
+static const char* buf_name(const p3_ctx* c, const DevBuf& b) {
+#define NM(f) \
+  if (&b == &c->f) return #f;
+  NM(fw) NM(rcw) NM(endm) NM(S) NM(P) NM(tkeys) NM(tcounts) NM(ckeys) NM(ccounts) NM(part) NM(solid) NM(kpart) NM(dkeys)
+  NM(ppart) NM(rx_part_buf) NM(or_tmp) NM(apart) NM(part8c) NM(klpart) NM(dall) NM(lpart) NM(part8) NM(tpos) NM(tsrc)
+  NM(singles) NM(ns_recv) NM(ns_part) NM(bloom) NM(seeds) NM(seed_part) NM(seed_set) NM(xg_buf) NM(owned_bases)
+#undef NM
+  return "?";
+}
+
 int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
   if (b.bytes >= bytes && b.p) return P3_OK;
   if (c->arena_p && lendable(c, b)) {
@@ -67,7 +78,7 @@ int ensure(p3_ctx* c, DevBuf& b, size_t bytes) {
     e = hipMalloc(&b.p, bytes ? bytes : 16);
   }
   if (trace && bytes >= (256u << 20))
-    fprintf(stderr, "[p3] hipMalloc %.2f GiB: %.1f ms\n", (double)bytes / (1u << 30),
+    fprintf(stderr, "[p3] rank %u %s: hipMalloc %.2f GiB: %.1f ms\n", c->rank, buf_name(c, b), (double)bytes / (1u << 30),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   if (e != hipSuccess) {
     b.p = nullptr;

@@ -5,6 +5,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
+#include <mutex>
+
 #include "p3_ctx.h"
 
 using namespace p3i;
@@ -19,6 +22,63 @@ struct p3_comm {
   ncclComm_t nccl = nullptr;
   int device = 0;
   u64* d_small = nullptr;  // device staging for the small host-side reductions
+  // member of a group of ranks inside one process (p3_group)
+  p3_group* group = nullptr;
+  uint32_t local = 0;
+};
+
+// Several protocol ranks in ONE process: v contexts on one GPU, one host thread each ("virtual ranks": a GPU whose shard
+// exceeds what one rank's 30-bit positions address hosts several).  Rank ids are process-major: process p of W hosts
+// p * v ... p * v + v - 1.  A collective among the W * v ranks = copies between the local members' device buffers (every
+// member pulls its own blocks on its own stream) + ONE collective of the outer communicator between the processes, issued
+// by local member 0 over packed staging buffers.  Members meet at a barrier on entry and on exit; a member that fails
+// aborts the barrier so that the others return P3_ECOMM instead of waiting for ever.
+struct p3_group {
+  uint32_t v = 1, W = 1, p = 0;
+  p3_comm* outer = nullptr;
+  struct Slot {
+    const void* send = nullptr;
+    const u64 *soff = nullptr, *scnt = nullptr;
+    void* recv = nullptr;
+    const u64 *roff = nullptr, *rcnt = nullptr;
+    u32 elem = 0;
+    u64 bytes = 0;
+    u64* vals = nullptr;
+    u32 n = 0;
+  } slot[P3_MAX_RANKS];
+  u64 red[64];
+  void *pack_send = nullptr, *pack_recv = nullptr;
+  u64 pack_send_bytes = 0, pack_recv_bytes = 0;
+  // The Bloom stage's scratch buffers (k-mer and position partitions, distinct k-mers: two thirds of a member's
+  // footprint, ~60 bytes per window) live only inside p3_make_bloom, and the members' kernels share one GPU anyway:
+  // the members take turns (bloom_mu) and carve those buffers from ONE arena instead of holding a set each.
+  std::mutex bloom_mu;
+  void* arena = nullptr;
+  u64 arena_bytes = 0, arena_want = 0;
+  // reusable barrier with abort
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t waiting = 0;
+  u64 generation = 0;
+  bool aborted = false;
+  bool wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (aborted) return false;
+    const u64 g = generation;
+    if (++waiting == v) {
+      waiting = 0;
+      generation++;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(lk, [&] { return generation != g || aborted; });
+    return generation != g;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(mu);
+    aborted = true;
+    cv.notify_all();
+  }
 };
 
 namespace {
@@ -85,8 +145,14 @@ int cfail(p3_comm* cm, int code, const std::string& what) {
   } while (0)
 
 // ---- the three collectives ------------------------------------------------------------------------------------------
+int group_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
+               u32 elem, hipStream_t st);
+int group_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hipStream_t st);
+int group_allreduce(p3_comm* cm, u64* v, u32 n, int op, hipStream_t st);
+
 int comm_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
               u32 elem, hipStream_t st) {
+  if (cm->group) return group_a2av(cm, d_send, soff, scnt, d_recv, roff, rcnt, elem, st);
   if (cm->use_cb) {
     if (cm->cb.all_to_all_v(cm->cb.user, d_send, soff, scnt, d_recv, roff, rcnt, elem, (void*)st))
       return cfail(cm, P3_ECOMM, "all_to_all_v callback failed");
@@ -104,6 +170,7 @@ int comm_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt,
 }
 
 int comm_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hipStream_t st) {
+  if (cm->group) return group_allgather(cm, d_send, d_recv, bytes, st);
   if (cm->use_cb) {
     if (cm->cb.all_gather(cm->cb.user, d_send, d_recv, bytes, (void*)st)) return cfail(cm, P3_ECOMM, "all_gather callback failed");
     return P3_OK;
@@ -113,6 +180,7 @@ int comm_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hip
 }
 
 int comm_allreduce(p3_comm* cm, u64* v, u32 n, int op, hipStream_t st) {
+  if (cm->group) return group_allreduce(cm, v, n, op, st);
   if (cm->use_cb) {
     if (cm->cb.all_reduce_u64(cm->cb.user, v, n, op)) return cfail(cm, P3_ECOMM, "all_reduce callback failed");
     return P3_OK;
@@ -124,6 +192,182 @@ int comm_allreduce(p3_comm* cm, u64* v, u32 n, int op, hipStream_t st) {
     return cfail(cm, P3_EHIP, "staging copy back");
   return P3_OK;
 }
+
+
+// ---- the same three among the members of a p3_group (+ the outer communicator between processes) -------------------------
+#define GHIP(cm, expr)                                                                                   \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      (cm)->group->abort();                                                                              \
+      return cfail((cm), P3_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    }                                                                                                    \
+  } while (0)
+#define GWAIT(cm)                                                                                        \
+  do {                                                                                                   \
+    if (!(cm)->group->wait()) return cfail((cm), P3_ECOMM, "another member of the group failed");        \
+  } while (0)
+
+int group_grow(p3_comm* cm, void*& buf, u64& have, u64 want) {
+  if (want <= have) return P3_OK;
+  if (buf) GHIP(cm, hipFree(buf));
+  buf = nullptr;
+  have = 0;
+  GHIP(cm, hipMalloc(&buf, want + (want >> 3) + 256));
+  have = want + (want >> 3) + 256;
+  return P3_OK;
+}
+
+// the part of an all-to-all that leaves the process (member 0, after every member published its slot): blocks are packed
+// per peer process as [local source s][its destination member d], which is the order the peer unpacks
+int group_remote_a2av(p3_comm* cm, u32 elem, hipStream_t st) {
+  p3_group* g = cm->group;
+  const u32 v = g->v, W = g->W, p = g->p;
+  u64 soff[P3_MAX_RANKS], scnt[P3_MAX_RANKS], roff[P3_MAX_RANKS], rcnt[P3_MAX_RANKS];
+  u64 sb = 0, rb = 0;
+  for (u32 q = 0; q < W; q++) {
+    soff[q] = sb;
+    roff[q] = rb;
+    if (q != p)
+      for (u32 s = 0; s < v; s++)
+        for (u32 d = 0; d < v; d++) {
+          sb += g->slot[s].scnt[q * v + d] * elem;  // local s -> member d of process q
+          rb += g->slot[d].rcnt[q * v + s] * elem;  // member s of process q -> local d
+        }
+    scnt[q] = sb - soff[q];
+    rcnt[q] = rb - roff[q];
+  }
+  int rc;
+  if ((rc = group_grow(cm, g->pack_send, g->pack_send_bytes, sb))) return rc;
+  if ((rc = group_grow(cm, g->pack_recv, g->pack_recv_bytes, rb))) return rc;
+  u64 at = 0;
+  for (u32 q = 0; q < W; q++) {
+    if (q == p) continue;
+    for (u32 s = 0; s < v; s++)
+      for (u32 d = 0; d < v; d++) {
+        const p3_group::Slot& S = g->slot[s];
+        const u64 n = S.scnt[q * v + d] * elem;
+        if (n) GHIP(cm, hipMemcpyAsync((char*)g->pack_send + at, (const char*)S.send + S.soff[q * v + d] * elem, n, hipMemcpyDeviceToDevice, st));
+        at += n;
+      }
+  }
+  if ((rc = comm_a2av(g->outer, g->pack_send, soff, scnt, g->pack_recv, roff, rcnt, 1, st))) {
+    g->abort();
+    return cfail(cm, rc, "outer communicator: " + g->outer->err);
+  }
+  at = 0;
+  for (u32 q = 0; q < W; q++) {
+    if (q == p) continue;
+    for (u32 s = 0; s < v; s++)
+      for (u32 d = 0; d < v; d++) {
+        const p3_group::Slot& D = g->slot[d];
+        const u64 n = D.rcnt[q * v + s] * elem;
+        if (n) GHIP(cm, hipMemcpyAsync((char*)D.recv + D.roff[q * v + s] * elem, (const char*)g->pack_recv + at, n, hipMemcpyDeviceToDevice, st));
+        at += n;
+      }
+  }
+  return P3_OK;
+}
+
+int group_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
+               u32 elem, hipStream_t st) {
+  p3_group* g = cm->group;
+  const u32 v = g->v, i = cm->local, me = g->p * v + i;
+  GHIP(cm, hipStreamSynchronize(st));  // what this member sends is complete before anybody reads it
+  p3_group::Slot& mine = g->slot[i];
+  mine.send = d_send;
+  mine.soff = soff;
+  mine.scnt = scnt;
+  mine.recv = d_recv;
+  mine.roff = roff;
+  mine.rcnt = rcnt;
+  mine.elem = elem;
+  GWAIT(cm);
+  for (u32 s = 0; s < v; s++) {  // pull this member's blocks from the local members
+    const p3_group::Slot& S = g->slot[s];
+    const u32 gs = g->p * v + s;
+    if (S.elem != elem || S.scnt[me] != rcnt[gs]) {
+      g->abort();
+      return cfail(cm, P3_ECOMM, "all-to-all: the members disagree about a block size");
+    }
+    const u64 n = rcnt[gs] * elem;
+    if (n) GHIP(cm, hipMemcpyAsync((char*)d_recv + roff[gs] * elem, (const char*)S.send + S.soff[me] * elem, n, hipMemcpyDeviceToDevice, st));
+  }
+  if (g->W > 1 && i == 0) {
+    int rc = group_remote_a2av(cm, elem, st);
+    if (rc) return rc;
+  }
+  GHIP(cm, hipStreamSynchronize(st));
+  GWAIT(cm);  // every copy out of and into every member's buffers is done
+  return P3_OK;
+}
+
+int group_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hipStream_t st) {
+  p3_group* g = cm->group;
+  const u32 v = g->v, i = cm->local;
+  GHIP(cm, hipStreamSynchronize(st));
+  g->slot[i].send = d_send;
+  g->slot[i].bytes = bytes;
+  GWAIT(cm);
+  if (g->W == 1) {
+    for (u32 s = 0; s < v; s++) {
+      if (g->slot[s].bytes != bytes) {
+        g->abort();
+        return cfail(cm, P3_ECOMM, "all-gather: the members disagree about the size");
+      }
+      GHIP(cm, hipMemcpyAsync((char*)d_recv + s * bytes, g->slot[s].send, bytes, hipMemcpyDeviceToDevice, st));
+    }
+  } else {
+    if (i == 0) {
+      int rc;
+      if ((rc = group_grow(cm, g->pack_send, g->pack_send_bytes, (u64)v * bytes))) return rc;
+      if ((rc = group_grow(cm, g->pack_recv, g->pack_recv_bytes, (u64)g->W * v * bytes))) return rc;
+      for (u32 s = 0; s < v; s++)
+        GHIP(cm, hipMemcpyAsync((char*)g->pack_send + s * bytes, g->slot[s].send, bytes, hipMemcpyDeviceToDevice, st));
+      if ((rc = comm_allgather(g->outer, g->pack_send, g->pack_recv, (u64)v * bytes, st))) {
+        g->abort();
+        return cfail(cm, rc, "outer communicator: " + g->outer->err);
+      }
+      GHIP(cm, hipStreamSynchronize(st));
+    }
+    GWAIT(cm);  // the gathered bytes are in the staging buffer
+    GHIP(cm, hipMemcpyAsync(d_recv, g->pack_recv, (u64)g->W * v * bytes, hipMemcpyDeviceToDevice, st));
+  }
+  GHIP(cm, hipStreamSynchronize(st));
+  GWAIT(cm);
+  return P3_OK;
+}
+
+int group_allreduce(p3_comm* cm, u64* vals, u32 n, int op, hipStream_t st) {
+  p3_group* g = cm->group;
+  if (n > 64) return cfail(cm, P3_EBADARG, "all_reduce: at most 64 values");
+  g->slot[cm->local].vals = vals;
+  g->slot[cm->local].n = n;
+  GWAIT(cm);
+  if (cm->local == 0) {
+    for (u32 j = 0; j < n; j++) {
+      u64 a = g->slot[0].vals[j];
+      for (u32 s = 1; s < g->v; s++) {
+        const u64 b = g->slot[s].vals[j];
+        a = op == 0 ? (a > b ? a : b) : a + b;
+      }
+      g->red[j] = a;
+    }
+    if (g->W > 1) {
+      int rc = comm_allreduce(g->outer, g->red, n, op, st);
+      if (rc) {
+        g->abort();
+        return cfail(cm, rc, "outer communicator: " + g->outer->err);
+      }
+    }
+  }
+  GWAIT(cm);
+  for (u32 j = 0; j < n; j++) vals[j] = g->red[j];
+  GWAIT(cm);  // (red is rewritten by the next reduction)
+  return P3_OK;
+}
+#undef GHIP
+#undef GWAIT
 
 // counts every rank will send me, given what I send to every rank (n_ranks values each way)
 int exchange_counts(p3_ctx* c, p3_comm* cm, const u64* send, u64* recv) {
@@ -192,6 +436,43 @@ int p3_comm_create_callbacks(p3_comm** out, const p3_comm_callbacks* cb, uint32_
   return P3_OK;
 }
 
+int p3_group_create(p3_group** out, uint32_t n_local, p3_comm* outer) {
+  const uint32_t W = outer ? outer->n_ranks : 1;
+  if (!out || n_local == 0 || (u64)n_local * W > P3_MAX_RANKS || (outer && outer->group)) return P3_EBADARG;
+  p3_group* g = new p3_group();
+  g->v = n_local;
+  g->W = W;
+  g->p = outer ? outer->rank : 0;
+  g->outer = outer;
+  *out = g;
+  return P3_OK;
+}
+
+int p3_group_destroy(p3_group* g) {
+  if (!g) return P3_EBADARG;
+  if (g->pack_send) (void)hipFree(g->pack_send);
+  if (g->pack_recv) (void)hipFree(g->pack_recv);
+  if (g->arena) (void)hipFree(g->arena);
+  delete g;
+  return P3_OK;
+}
+
+int p3_comm_create_member(p3_comm** out, p3_group* g, uint32_t local_index) {
+  if (!out || !g || local_index >= g->v) return P3_EBADARG;
+  p3_comm* cm = new p3_comm();
+  cm->rank = g->p * g->v + local_index;
+  cm->n_ranks = g->W * g->v;
+  cm->group = g;
+  cm->local = local_index;
+  *out = cm;
+  return P3_OK;
+}
+
+int p3_comm_all_reduce_u64(p3_comm* cm, uint64_t* values, uint32_t n, int op) {
+  if (!cm || !values || n == 0 || n > 64 || (op != 0 && op != 1)) return P3_EBADARG;
+  return comm_allreduce(cm, values, n, op, nullptr);
+}
+
 int p3_comm_destroy(p3_comm* cm) {
   if (!cm) return P3_EBADARG;
   if (cm->nccl) (void)rccl().CommDestroy(cm->nccl);
@@ -200,8 +481,50 @@ int p3_comm_destroy(p3_comm* cm) {
   return P3_OK;
 }
 
+static int run_pass_steps(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, uint32_t H);
+
+// p3_make_bloom of one member of a group, its scratch buffers carved from the group's arena (see p3_group)
+static int group_make_bloom(p3_ctx* c, p3_group* g, uint32_t k, uint64_t m_bits, uint32_t H) {
+  std::lock_guard<std::mutex> turn(g->bloom_mu);
+  DevBuf* lent[] = {&c->kpart, &c->klpart, &c->dkeys, &c->dall, &c->ppart};
+  const u64 guess = c->n_words * 32 * 64 + (256ull << 20);  // (measured: 62 bytes per window at 4 ranks)
+  const u64 want = g->arena_want > guess ? g->arena_want : guess;
+  if (g->arena_bytes < want) {  // (nobody holds a piece of it: borrowed buffers are forgotten when a turn ends)
+    if (g->arena) (void)hipFree(g->arena);
+    g->arena = nullptr;
+    g->arena_bytes = 0;
+    if (hipMalloc(&g->arena, want) == hipSuccess) g->arena_bytes = want;
+    else (void)hipGetLastError();  // (no arena: the buffers are allocated one by one, as without a group)
+  }
+  for (DevBuf* b : lent)
+    if (b->p && !b->borrowed) release(*b);  // a set of its own would shadow the arena
+  DevBuf owner;
+  owner.p = g->arena;
+  owner.bytes = g->arena_bytes;
+  int rc;
+  {
+    LendScope lend(c, owner);
+    rc = p3_make_bloom(c, k, m_bits, H);
+    u64 used = c->arena_used;
+    for (DevBuf* b : lent)
+      if (b->p && !b->borrowed) {  // did not fit: allocated on its own for this pass; the arena grows for the next
+        used += b->bytes;
+        release(*b);
+      }
+    if (used + used / 8 > g->arena_want && used > g->arena_bytes) g->arena_want = used + used / 8;
+  }
+  owner.p = nullptr;  // (the arena is the group's, not this DevBuf's)
+  return rc;
+}
+
 int p3_mr_run_pass(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, uint32_t H) {
   if (!c || !cm) return P3_EBADARG;
+  const int rc = run_pass_steps(c, cm, k, m_bits, H);
+  if (rc && cm->group) cm->group->abort();  // (the other members of the group would wait for this one otherwise)
+  return rc;
+}
+
+static int run_pass_steps(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, uint32_t H) {
   const u32 W = cm->n_ranks;
   int rc;
   HIPCHK(c, hipSetDevice(c->device));
@@ -288,7 +611,7 @@ int p3_mr_run_pass(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, uint32_t
   }
   // ---- Bloom: rank-local partial vector, then OR-merge (RCCL has no OR reduction: all-to-all of word chunks, local OR,
   //      all-gather of the merged chunks)
-  if ((rc = p3_make_bloom(c, k, m_bits, H))) return rc;
+  if ((rc = (cm->group && cm->group->v > 1) ? group_make_bloom(c, cm->group, k, m_bits, H) : p3_make_bloom(c, k, m_bits, H))) return rc;
   if (W > 1) {
     void* d_words;
     u64 n_words;

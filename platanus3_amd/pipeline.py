@@ -175,8 +175,23 @@ class TorchComm:
         return self._reduce(v, self.dist.ReduceOp.SUM)
 
 
+def native_rccl_comm(device, rank, world, group):
+    """the library's own RCCL communicator over the ranks of a torch.distributed job (the id travels over torch), or None"""
+    import torch.distributed as dist
+    try:
+        if dist.get_backend(group) != "nccl":
+            return None
+        obj = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        return capi.Comm.rccl(obj[0], rank, world, device)
+    except Exception as e:  # noqa: BLE001
+        import sys
+        print("platanus3_amd: in-library exchange unavailable (%s); using the torch.distributed protocol" % e, file=sys.stderr)
+        return None
+
+
 class Pipeline:
-    def __init__(self, device=0, rank=0, world=1, backend=None, group=None, force_protocol=False, comm=None):
+    def __init__(self, device=0, rank=0, world=1, backend=None, group=None, force_protocol=False, comm=None, native=None):
         self.rank, self.world, self.group = rank, world, group
         self.be = backend if backend is not None else HipBackend(device)
         self.ctx = getattr(self.be, "ctx", None)
@@ -193,23 +208,10 @@ class Pipeline:
         # The exchange INSIDE the library (p3_mr_run_pass over the library's own RCCL communicator: no Python, no torch
         # between the protocol steps) whenever this is a real multi-GPU job; the Python protocol below remains for the
         # CPU stand-in, the loopback harness, and as the fallback when librccl cannot be opened.  P3_PY_EXCHANGE=1 forces it.
-        self.native = None
-        if (world > 1 and backend is None and comm is None and self.ctx is not None
+        self.native = native  # (a member communicator of a capi.Group: VirtualRanks)
+        if (native is None and world > 1 and backend is None and comm is None and self.ctx is not None
                 and os.environ.get("P3_PY_EXCHANGE", "0") != "1"):
-            self.native = self._native_comm(device, rank, world, group)
-
-    def _native_comm(self, device, rank, world, group):
-        import torch.distributed as dist
-        try:
-            if dist.get_backend(group) != "nccl":
-                return None
-            obj = [capi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(obj, src=0, group=group)
-            return capi.Comm.rccl(obj[0], rank, world, device)
-        except Exception as e:  # noqa: BLE001
-            import sys
-            print("platanus3_amd: in-library exchange unavailable (%s); using the torch.distributed protocol" % e, file=sys.stderr)
-            return None
+            self.native = native_rccl_comm(device, rank, world, group)
 
     def load_reads(self, bases, offsets, min_len):
         self.be.load_reads(bases, offsets, min_len)
@@ -338,8 +340,10 @@ class Pipeline:
 # One rank of the multi-rank protocol takes at most 2^30 window positions (its partition records address a window by a
 # 30-bit position).  BASELINE config #3 (50 M x 150 bp) sharded over 2 or 4 GPUs exceeds that per GPU, so a GPU then hosts
 # several VIRTUAL ranks: `per_rank` contexts, each with its own slice of the GPU's shard, driven by threads.  The protocol
-# runs unchanged over V = world x per_rank ranks; collectives between virtual ranks are copies inside one process and
-# torch.distributed (RCCL) between processes.  Virtual rank ids are process-major: process p hosts p * per_rank ... .
+# runs unchanged over V = world x per_rank ranks.  On the GPU the exchange is the library's (p3_group: copies between the
+# local members' device buffers + one RCCL collective between the processes, no Python between the protocol steps); the
+# Python HybridComm below does the same for the CPU stand-in backends of the gloo tests and the few scalar reductions
+# of the results.  Virtual rank ids are process-major: process p hosts p * per_rank ... .
 
 class _HybridWorld:
     def __init__(self, per_rank, rank, world, group=None):
@@ -477,9 +481,16 @@ class VirtualRanks:
         self.hw = _HybridWorld(per_rank, rank, world, group)
         self.pipes = []
         per = n_reads // per_rank
+        self.outer, self.native_group = None, None
+        if backends is None and os.environ.get("P3_PY_EXCHANGE", "0") != "1":
+            self.outer = native_rccl_comm(device, rank, world, group) if world > 1 else None
+            if world == 1 or self.outer is not None:
+                self.native_group = capi.Group(per_rank, self.outer)
         for i in range(per_rank):
             be = backends[i] if backends is not None else None
-            pipe = Pipeline(device=device, rank=rank * per_rank + i, world=world * per_rank, backend=be, comm=self.hw.comm(i))
+            member = capi.Comm.member(self.native_group, i) if self.native_group is not None else None
+            pipe = Pipeline(device=device, rank=rank * per_rank + i, world=world * per_rank, backend=be, comm=self.hw.comm(i),
+                            native=member)
             if reads is not None:
                 b, o = reads[i]
             else:
@@ -527,9 +538,14 @@ class VirtualRanks:
         return {"n_solid": self._each(lambda p: p.comm.all_reduce_sum(p.ctx.count_stats()["n_solid"]))[0]}
 
     def parallelism(self):
-        return "reads sharded by index x%d (%d protocol ranks per GPU)" % (self.world, self.v)
+        return "reads sharded by index x%d (%d protocol ranks per GPU%s)" % (
+            self.world, self.v, ", exchange inside the library" if self.native_group is not None else "")
 
     def close(self):
         for p in self.pipes:
             if p.ctx is not None:
-                p.ctx.close()
+                p.close()
+        if self.native_group is not None:
+            self.native_group.close()
+        if self.outer is not None:
+            self.outer.close()

@@ -142,6 +142,85 @@ def test_run_pass_through_callbacks(oracle, world, k, gate, agg):
     _check_union(oracle, b, o, k, m, H, results)
 
 
+@pytest.mark.parametrize("procs,v,k,gate", [(1, 4, 31, 2), (1, 2, 31, 1), (2, 2, 31, 2), (2, 4, 27, 2), (4, 2, 41, 1)])
+def test_run_pass_in_groups(oracle, procs, v, k, gate):
+    """p3_group: v protocol ranks per "process" (a GPU whose shard exceeds one rank's 2^30 positions hosts several), `procs`
+    processes joined by an outer communicator (callbacks here, RCCL in a job) that only member 0 of each group uses.
+    All procs x v ranks are threads of this one process on this one GPU."""
+    V = procs * v
+    n_reads = 24000
+    per = n_reads // V
+    b, o = synth.reads(seed=63, total_reads=n_reads, read_len=150)
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    pw = PtrWorld(procs)
+    outers = [capi.Comm.callbacks(p, procs, *pw.callbacks(p)) if procs > 1 else None for p in range(procs)]
+    groups = [capi.Group(v, outers[p]) for p in range(procs)]
+    results, errors = [None] * V, []
+
+    def worker(p, i):
+        r = p * v + i
+        try:
+            comm = capi.Comm.member(groups[p], i)
+            ctx = capi.Context(0)
+            ctx.set_option("gate_mode", gate)
+            bb = b[int(o[r * per]):int(o[(r + 1) * per])]
+            oo = o[r * per:(r + 1) * per + 1] - o[r * per]
+            ctx.load_reads(bb, oo, min_len=k)
+            ctx.mr_run_pass(comm, k, m, H)
+            ctx.mr_run_pass(comm, k, m, H)
+            assert comm.all_reduce([r, 1], "sum") == [V * (V - 1) // 2, V]
+            assert comm.all_reduce([r], "max") == [V - 1]
+            keys, counts = ctx.export_counts()
+            results[r] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            pw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(p, i)) for p in range(procs) for i in range(v)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in groups:
+        g.close()
+    for c in outers:
+        if c is not None:
+            c.close()
+    assert not errors, errors
+    _check_union(oracle, b, o, k, m, H, results)
+
+
+def test_group_member_failure_does_not_hang():
+    """a member that fails (no reads loaded) aborts the group: the other member returns an error instead of waiting"""
+    g = capi.Group(2, None)
+    b, o = synth.reads(seed=64, total_reads=4000, read_len=150)
+    errors = [None, None]
+
+    def worker(i):
+        comm = capi.Comm.member(g, i)
+        ctx = capi.Context(0)
+        try:
+            if i == 0:
+                ctx.load_reads(b, o, min_len=31)
+            ctx.mr_run_pass(comm, 31, 1 << 24, 3)
+        except capi.P3Error as e:
+            errors[i] = e
+        finally:
+            ctx.close()
+            comm.close()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert not any(t.is_alive() for t in th), "a group member is still waiting"
+    g.close()
+    assert errors[0] is not None and errors[1] is not None
+
+
 def test_cpp_host_drives_the_sharded_pass(tmp_path):
     """platanus3_amd/host/mr_demo.cpp: a C++ program -- one thread per GPU, the library's own RCCL communicators,
     p3_mr_run_pass -- with no Python in the loop (one GPU here; its numbers must equal the single-rank pass)."""

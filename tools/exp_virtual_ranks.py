@@ -1,0 +1,33 @@
+"""Time pipeline.VirtualRanks (several protocol ranks on ONE GPU) against the single-context pass on the same reads.
+usage: python tools/exp_virtual_ranks.py [total_reads] [per_rank] [k]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import bloom_sizing  # noqa: E402
+from platanus3_amd import synth  # noqa: E402
+from platanus3_amd.pipeline import Pipeline, VirtualRanks  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000000
+v = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
+m, H = bloom_sizing(n * 150, k)
+vr = VirtualRanks(device=0, rank=0, world=1, per_rank=v, seed=1, total_reads=n, first_read=0, n_reads=n)
+print("form:", vr.parallelism(), flush=True)
+for step in range(int(os.environ.get("VR_STEPS", "4"))):
+    t0 = time.perf_counter()
+    vr.run_pass(k, m, H)
+    print("virtual ranks pass %d: %.1f ms" % (step, (time.perf_counter() - t0) * 1e3), flush=True)
+dv, pv = vr.global_distinct(), vr.passing_kmers()
+vr.close()
+pipe = Pipeline(device=0)
+b, o = synth.reads(seed=1, total_reads=n, first_read=0, n_reads=n, read_len=150)
+pipe.load_reads(b, o, min_len=21)
+for step in range(3):
+    t0 = time.perf_counter()
+    pipe.run_pass(k, m, H)
+    print("single context pass %d: %.1f ms" % (step, (time.perf_counter() - t0) * 1e3), flush=True)
+d1, p1 = pipe.global_distinct(), pipe.passing_kmers()
+print("distinct 21-mers: %d vs %d; passing windows: %d vs %d" % (dv, d1, pv, p1))
+assert dv == d1 and pv == p1
