@@ -82,7 +82,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     const u64 max_records = c->n_words * 32 + 16ull * P3_NWG * P3_NB;
     // the k-mer and probe partitions are rank-local (nothing of them is exchanged), so the estimated-capacity
     // form serves the multi-rank protocol as well
-    const bool est = c->est_ok && c->sizing_opt != 1;
+    const bool est = c->ad.est_ok && c->sizing_opt != 1;
     double mean_k = (double)wg_window_bound(c) / P3_NB;
     if (c->host_windows) mean_k = (double)c->host_windows * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
     if (c->pass_hint && c->pass_hint_k == k) mean_k = (double)c->pass_hint * 1.02 / ((double)P3_NB * active_wgs(c->n_words));
@@ -381,14 +381,14 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   }
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
   if (c->kphase == 2 && hall[27]) {
-    c->kcollect_ok = false;  // (the per-chunk form still works: no need to give up the estimates altogether)
+    c->ad.collection_overflowed();  // (the per-chunk form still works: no need to give up the estimates altogether)
     return fail(c, P3_ERETRY_INTERNAL, "collected k-mer partition: estimated segment capacity exceeded");
   }
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     est_overflowed(c);
     c->counted = c->counted && !hall[26];
     return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded (Bloom stage: k-mer/probe partition %llu, count stage %llu; level now %u%s)",
-                (unsigned long long)hall[25], (unsigned long long)hall[26], c->est_boost, c->est_ok ? "" : ", exact next");
+                (unsigned long long)hall[25], (unsigned long long)hall[26], c->ad.est_boost, c->ad.est_ok ? "" : ", exact next");
   }
   if (c->spec) {
     // the single synchronisation point of a speculative pass: were last pass's splits still good?
@@ -450,7 +450,7 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
   // Every chunk sees most of the genome's k-mers again, so probing chunk by chunk repeats the probe work `chunks`
   // times.  Instead the chunks' distinct k-mers are collected, deduplicated once more (k_keys_scatter + the same
   // dedup machinery) and probed once.  A chunk whose keys do not fit the collection is probed directly.
-  const bool collect = c->est_ok && c->sizing_opt != 1 && c->bloom_mode_opt != 1 && c->kcollect_opt && c->kcollect_ok &&
+  const bool collect = c->ad.est_ok && c->sizing_opt != 1 && c->bloom_mode_opt != 1 && c->kcollect_opt && c->ad.kcollect_ok &&
                        (c->chunks >= 4 || c->kcollect_opt == 2);  // (two chunks: the extra dedup costs more than it saves)
   c->dall_n = 0;
   c->dall_cap = 0;
@@ -660,7 +660,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
   // Speculative pass: when the previous pass over the SAME reads and parameters succeeded, its sub-bucket
   // splits and buffer sizes are reused and the whole pass is enqueued with ONE synchronisation at the end
   // (overflow flags are checked there; on any surprise the pass is simply repeated the careful way).
-  const bool can_spec = c->hint_valid && c->hint_epoch == c->reads_epoch && c->hint_k == k && c->hint_m == m_bits &&
+  const bool can_spec = c->ad.hint_valid && c->hint_epoch == c->reads_epoch && c->hint_k == k && c->hint_m == m_bits &&
                         c->hint_H == H && c->n_ranks == 1 && c->count_mode_opt != 1 && c->gate_mode_opt != 1 &&
                         c->bloom_mode_opt != 1 && !c->dbg_opt;
   if (can_spec) {
@@ -692,7 +692,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
       if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
       return P3_OK;
     }
-    c->hint_valid = false;
+    c->ad.hint_valid = false;
     if (rc != P3_ERETRY_INTERNAL) return rc;
     (void)hipStreamSynchronize(c->stream);  // fall through to the careful path
   }
@@ -701,7 +701,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, c->ev[0], c->ev[5]) == hipSuccess) c->tm.ms_total = ms;
   if (c->count_mode == 2 && c->gate_mode == 2 && c->bloom_mode == 3 && c->chunks == 1) {
-    c->hint_valid = true;
+    c->ad.hint_valid = true;
     c->hint_epoch = c->reads_epoch;
     c->hint_sbits = c->sbits;
     c->hint_xbits = c->split_xbits;

@@ -139,6 +139,15 @@ ModM make_modm(u64 m) {
   return mm;
 }
 
+// THE reset point of everything a context learnt from earlier passes: new reads (p3_load_reads*) and the drop_hints option
+void forget_learnt(p3_ctx* c, bool new_reads) {
+  c->ad.reset(new_reads);
+  c->ksbits_epoch = ~0ull;  // sub-bucket splits of the k-mer sets and of the run-record count
+  c->sbits_epoch = ~0ull;
+  c->pass_hint = 0;         // passing windows of the last Bloom stage (sizes its partitions)
+  c->kxg = 0;
+}
+
 int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->n_reads = n_reads;
   c->n_bases = n_bases;
@@ -149,17 +158,9 @@ int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {
   c->packed = c->counted = c->bloomed = false;
   c->graphed = false;
   c->reads_epoch++;
-  c->hint_valid = false;
   free_outgrown(c);
-  c->est_ok = true;
-  c->sk_ok = true;
-  c->sk_boost = 0;
-  c->chunk_ok = true;
-  c->est_boost = 0;
-  c->kcollect_ok = true;
-  c->distinct_cap = 0;
+  forget_learnt(c, true);
   c->host_windows = 0;
-  c->pass_hint = 0;
   return P3_OK;
 }
 
@@ -292,7 +293,7 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     c->ksplit_opt = (int)value;
   } else if (n == "distinct_cap") {  // tests: entries of the estimate-sized count table outputs (position chunks)
     if (value < 0) return fail(c, P3_EBADARG, "distinct_cap must be >= 0");
-    c->distinct_cap = (u64)value;
+    c->ad.distinct_cap = (u64)value;
   } else if (n == "chunks") {
     if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16))
       return fail(c, P3_EBADARG, "chunks must be 0, 1, 2, 4, 8 or 16");
@@ -306,17 +307,7 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "drop_hints") {
     // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
     // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
-    c->hint_valid = false;
-    c->ksbits_epoch = ~0ull;
-    c->sbits_epoch = ~0ull;
-    c->pass_hint = 0;
-    c->kxg = 0;
-    c->est_boost = 0;
-    c->est_ok = true;
-    c->chunk_ok = true;
-    c->kcollect_ok = true;
-    c->sk_ok = true;
-    c->sk_boost = 0;
+    forget_learnt(c, false);
   } else if (n == "run_records") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "run_records must be 0 (auto), 1 (never) or 2 (wherever they apply)");
     c->sk_opt = (int)value;
@@ -352,9 +343,9 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "rs_log2") *value = c->rs_log2;
   else if (n == "split_xbits") *value = c->split_xbits;
   else if (n == "chunks") *value = c->chunks;
-  else if (n == "est_fallbacks") *value = (int64_t)c->est_fallbacks;
+  else if (n == "est_fallbacks") *value = (int64_t)c->ad.fallbacks;
   else if (n == "kmer_groups") *value = (int64_t)c->kgroups;
-  else if (n == "est_level") *value = c->est_ok ? (int64_t)c->est_boost : 3;  // 0..2 = boost level in use, 3 = exact
+  else if (n == "est_level") *value = c->ad.est_ok ? (int64_t)c->ad.est_boost : 3;  // 0..2 = boost level in use, 3 = exact
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);

@@ -59,15 +59,13 @@ u32 segcap_for(const p3_ctx* c, double mean) {
   // (the constant slack matters for tiny means only; every 16 records of capacity is 16 records of gap the readers
   // step over, ~2.4 % of a 672-record segment)
   static const double boost[3] = {0.0, 0.5, 1.5};
-  const double v = mean * (1.0 + boost[c->est_boost < 3 ? c->est_boost : 2]) + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) +
+  const double v = mean * (1.0 + boost[c->ad.est_boost < 3 ? c->ad.est_boost : 2]) + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) +
                    (mean >= 256.0 ? 16.0 : 32.0);
   return ((u32)v + 15u) & ~15u;
 }
 
 // an estimated-capacity segment overflowed: next boost level, or no more estimates for these reads
 void est_overflowed(p3_ctx* c) {
-  c->est_fallbacks++;
-  if (!c->est_ok) c->chunk_ok = false;  // (already on exact first-level offsets: a second-level partition overflowed)
   // (large inputs: the position partition is 8 B per window, 2.5x that at level 2 -- only while it stays within a
   // third of the device memory, 33 M reads of 150 bp on 288 GB)
   const u64 positions = (c->n_words_all ? c->n_words_all : c->n_words) * 32;
@@ -76,11 +74,10 @@ void est_overflowed(p3_ctx* c) {
   if (positions > (1ull << 31) &&
       (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || (double)positions * 8.0 * 2.5 > 0.35 * (double)mem_total))
     top = 1;
-  if (c->est_boost < top && c->boost_opt != 1) c->est_boost++;
-  else c->est_ok = false;
+  c->ad.estimate_overflowed(top, c->boost_opt != 1);
 }
 
-bool est_mode(const p3_ctx* c) { return c->n_ranks == 1 && !c->protocol && c->est_ok && c->sizing_opt != 1; }
+bool est_mode(const p3_ctx* c) { return c->n_ranks == 1 && !c->protocol && c->ad.est_ok && c->sizing_opt != 1; }
 
 
 
@@ -91,21 +88,20 @@ bool sk_on(const p3_ctx* c) {
   // Measured on MI355X (profiles/r02_sk_*): the record form moves 3x fewer bytes but its consumers are bound by
   // instruction issue and LDS latency, not by HBM -- 2.85 ms per config-#2 pass against 2.6 ms for the per-window
   // kernels -- so it is used only when asked for (run_records = 2).
-  if (c->sk_opt != 2 || !c->sk_ok) return false;
+  if (c->sk_opt != 2 || !c->ad.sk_ok) return false;
   return est_mode(c) && c->chunks == 1 && c->n_words * 32 <= (1ull << 30);
 }
 // records per (bucket, workgroup) segment for `windows` windows cut into runs: a run ends where the minimizer changes
 // (every (w + 1) / 2 windows for random sequence, w = m-mers per k-mer), at the word boundary (1 / 32) and at a read
 // end; buckets of minimizers are less even than buckets of hashed keys (+25 %).  sk_boost = 1: one record per window.
 u32 sk_segcap_for(const p3_ctx* c, double windows, u32 w_mmers, u32 fbits) {
-  const double per_window = c->sk_boost ? 1.0 : (2.0 / (w_mmers + 1) + 1.0 / 32 + 1.0 / 100) * (fbits ? 1.35 : 1.25);
+  const double per_window = c->ad.sk_boost ? 1.0 : (2.0 / (w_mmers + 1) + 1.0 / 32 + 1.0 / 100) * (fbits ? 1.35 : 1.25);
   const double mean = windows * per_window / ((double)(P3_NB << fbits) * active_wgs(c->n_words));
   return ((u32)(mean + 6.0 * std::sqrt(mean) + 32.0) + 15u) & ~15u;
 }
 // the run-record form did not fit (a full segment, a count beyond the slot field, unknown bases): next level or off
 void sk_failed(p3_ctx* c, bool retry_larger) {
-  if (retry_larger && c->sk_boost == 0) c->sk_boost = 1;
-  else c->sk_ok = false;
+  c->ad.run_records_failed(retry_larger);
 }
 u32 sk_initial_sbits(u64 windows, u32 ts_log2) {
   // <= 6 instances per usable slot (7/8 of the table): ~30x coverage with sequencing errors gives one distinct key
@@ -242,7 +238,7 @@ int repartition_rx(p3_ctx* c) {
 int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb);
 
 // k_split with per-cell capacities (k_cell_sample / k_var_caps): from the first overflow of an estimate on
-bool var_caps_on(const p3_ctx* c) { return c->est_boost >= 1 && c->varcap_opt != 0; }
+bool var_caps_on(const p3_ctx* c) { return c->ad.est_boost >= 1 && c->varcap_opt != 0; }
 float var_seg_scale() { return 64.0f * 1.15f / (float)P3_NWG; }  // sampled vectors of a cell -> records of one segment, + 15 %
 float var_boost_mul(const p3_ctx*) { return 1.0f; }  // (the uniform capacity, the lower bound of every cell, carries the level's boost)
 int var_caps_prepare(p3_ctx* c) {
@@ -275,7 +271,7 @@ int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
-  if (c->n_ranks > 1 && c->part_pos && c->est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
+  if (c->n_ranks > 1 && c->part_pos && c->ad.est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
     // position records: owner-side split through the stager with estimated capacities (k_split; no histogram pass).
     // From an 8-way sub-bucket split on, the owned buckets are processed in 2^xg groups with xg more split bits
     // instead, so that every cell is read once.  An overflow of the estimate clears est_ok and lands in the exact
@@ -410,7 +406,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   // worst case one entry per record; position chunks (tens of GB of records) size the table from an estimate of the
   // distinct keys instead -- the count kernel refuses to write past it and the stage is then repeated larger
   u64 maxd = c->rx_records + 1;
-  if (chunked && c->distinct_cap && c->distinct_cap < maxd) maxd = c->distinct_cap;
+  if (chunked && c->ad.distinct_cap && c->ad.distinct_cap < maxd) maxd = c->ad.distinct_cap;
   if ((rc = ensure(c, c->ckeys, maxd * 8))) return rc;
   if ((rc = ensure(c, c->ccounts, maxd * 4))) return rc;
   if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
@@ -486,7 +482,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
                 (unsigned long long)h[26], (unsigned long long)h[27], var_caps_on(c) ? "on" : "off");
   }
   if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
-    c->distinct_cap = maxd * 2;
+    c->ad.distinct_cap = maxd * 2;
     return count_split(c, xg, sbits, overflowed, max_solid_sb);
   }
   *overflowed = h[3] != 0;
@@ -705,8 +701,8 @@ int do_count_part(p3_ctx* c, bool* overflowed) {
 u32 chunks_for(const p3_ctx* c) {  // 0 = the chunked form does not apply
   // (est_ok false = heavy skew: the chunks' first-level partitions then use exact offsets, the second-level ones
   // sampled per-cell capacities; only when that fails too -- chunk_ok -- do the direct kernels take over)
-  if (c->chunk_opt == 1 || c->n_ranks != 1 || c->protocol || !c->chunk_ok || c->sizing_opt == 1) return 0;
-  if (!c->est_ok && !var_caps_on(c)) return 0;
+  if (c->chunk_opt == 1 || c->n_ranks != 1 || c->protocol || !c->ad.chunk_ok || c->sizing_opt == 1) return 0;
+  if (!c->ad.est_ok && !var_caps_on(c)) return 0;
   if (c->count_mode_opt == 1 || c->gate_mode_opt == 1 || c->bloom_mode_opt == 1) return 0;
   const u64 pos = c->n_words * 32;
   if (c->chunk_opt >= 2) return (pos / (u32)c->chunk_opt <= (1ull << 30)) ? (u32)c->chunk_opt : 0;
@@ -772,7 +768,7 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   c->part_pos = true;
   // count table outputs: a quarter of the records to start with (30x coverage gives 1/7, 1 % errors on long reads
   // 1/4.5); the count kernel reports when that is too small and the size doubles
-  if (!c->distinct_cap) c->distinct_cap = total / 4 + (1ull << 20);
+  if (!c->ad.distinct_cap) c->ad.distinct_cap = total / 4 + (1ull << 20);
   // split bits: cells of <= ~96 Ki records (uncapped version of initial_sbits), at least log2(C) so that the split
   // kernel's item list (rows x sources) stays within 1024
   u32 xg = 0;

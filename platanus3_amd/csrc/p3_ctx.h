@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "platanus3_amd.h"
+#include "p3_adapt.h"
 #include "p3_kernels.h"
 #include "p3_kernels_part.h"
 #include "p3_kernels_bloom.h"
@@ -82,9 +83,7 @@ struct p3_ctx {
   int tsk_log2_opt = 14;
   int dbg_opt = 0;          // timing experiments only (results are wrong when non-zero)
   int sizing_opt = 0;       // 0 auto (estimated segment capacities on one rank), 1 exact (histogram + scan)
-  bool chunk_ok = true;     // cleared when the position-chunk form failed even with exact first-level offsets
-  u32 est_boost = 0;        // skew response: 0 / 1 / 2 = segment capacities of the estimate + 0 / 50 / 150 % of the mean
-  bool est_ok = true;       // cleared when an estimated segment overflowed at the last boost level (skewed keys) until new reads arrive    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
+  P3Adapt ad;               // the response to inputs that break an estimate: every such flag, one reset point (p3_adapt.h)    // LDS k-mer set slots per sub-bucket (NW=2 uses one less)
   u32 ksbits = 0, ksbits_k = 0;
   u64 ksbits_epoch = ~0ull;
   u32 sbits_sk = 0;          // sub-bucket split the run-record count needed for the reads of sbits_epoch
@@ -126,7 +125,6 @@ struct p3_ctx {
   int kphase = 0;
   u32 kgroups = 0;            // info: collected groups probed in the last chunked Bloom stage
   bool kcollect_pass = true;  // this pass: cleared by the first chunk when the collection would not fit in memory
-  bool kcollect_ok = true;   // cleared when the collected list's partition overflowed its estimate
   int boost_opt = 0;         // tests: 1 = no boost levels (an overflowing estimate goes straight to exact offsets)
   int lend_opt = 1;          // 1 = always lend the count partitions to the k-mer stage; 0 = only when memory is short
   int kgroup_opt = 0;        // tests: at most this many chunks per collected group (0 = as many as fit in memory)
@@ -134,13 +132,11 @@ struct p3_ctx {
   DevBuf dall;
   u64 dall_n = 0, dall_cap = 0;
   u64 k2ext_h[2] = {0, 0};
-  u64 distinct_cap = 0;      // entries of the count table outputs when sized from an estimate (position chunks)
   bool reparted_split = false;  // the owner-side re-partition used k_split (descriptors in seg_off2 / ghist2)
   u32 split_xbits = 0;      // > 0: the count stage runs the second-level partition (k_split) in 2^split_xbits groups
   int split_opt = 0;        // 0 = auto, 1 = never, 2..6 = force split_xbits = value - 1
   u32 hint_xbits = 0;
   DevBuf seg_off2, ghist2;
-  u64 est_fallbacks = 0;  // times an estimated-capacity partition overflowed and the stage was repeated exactly
   u32 xbits = 0;
   DevBuf lpart;
   // coverage gate: 1 = probe the solid-key regions per window, 2 = return path (non-solid positions come back
@@ -158,7 +154,7 @@ struct p3_ctx {
   p3_graph_stats gstats_{};
   std::vector<u64> g_seqoff_host;
   // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
-  bool spec = false, hint_valid = false;
+  bool spec = false;
   u32 hint_sbits = 1, hint_ksbits = 0, hint_k = 0, hint_H = 0;
   u64 hint_nsing = 0;
   u32 pass_hint_k = 0;
@@ -173,8 +169,6 @@ struct p3_ctx {
   // count that outgrew the 22-bit slot field): the per-window kernels then take over.  Off unless asked for: it
   // measured slower than the per-window kernels (see sk_on).
   int sk_opt = 0;
-  bool sk_ok = true;
-  u32 sk_boost = 0;          // 0 = expected run density, 1 = one record per window (worst case)
   bool part_sk = false;      // the current count partition holds run records (16 B)
   bool kpart_sk = false;     // ... and so does the current k-mer partition
   u32 sk_segcap = 0, sk_ksegcap = 0;
