@@ -71,6 +71,39 @@ struct Roller {
   inline u128 canon() const { return fwd <= rc ? fwd : rc; }  // src/BitCalc.cpp:47-54 (tie -> fwd)
 };
 
+// The same for keys beyond two words (65 <= k <= 128; the reference's k = 101, src/Assemble.cpp:40): the key as an
+// array of 64-bit words, word 0 least significant -- the layout of std::bitset<2k>.
+struct WideRoller {
+  int k, nw;
+  uint64_t fwd[4], rc[4];
+  explicit WideRoller(int k_) : k(k_), nw(nwords(k_)) {
+    for (int t = 0; t < 4; t++) fwd[t] = rc[t] = 0;
+  }
+  inline void push(char c) {
+    // fwd = ((fwd << 2) | code) & mask
+    for (int t = nw - 1; t > 0; t--) fwd[t] = (fwd[t] << 2) | (fwd[t - 1] >> 62);
+    fwd[0] = (fwd[0] << 2) | fwd_code(c);
+    const int top_bits = 2 * k - 64 * (nw - 1);
+    if (top_bits < 64) fwd[nw - 1] &= (1ULL << top_bits) - 1;
+    // rc = (rc >> 2) | code << (2k - 2)
+    for (int t = 0; t < nw - 1; t++) rc[t] = (rc[t] >> 2) | (rc[t + 1] << 62);
+    rc[nw - 1] = (rc[nw - 1] >> 2) | ((uint64_t)rc_code(c) << (top_bits - 2));
+  }
+  inline const uint64_t* canon() const {  // src/BitCalc.cpp:47-54: bit by bit from the top, tie -> fwd
+    for (int t = nw - 1; t >= 0; t--)
+      if (fwd[t] != rc[t]) return fwd[t] < rc[t] ? fwd : rc;
+    return fwd;
+  }
+};
+
+inline void decode_words(const uint64_t* key, int k, char* out) {  // GetStringKmer, src/BitCalc.cpp:56-65
+  static const char b2c[4] = {'A', 'C', 'G', 'T'};
+  for (int i = 0; i < k; i++) {
+    const int bit = 2 * (k - 1 - i);
+    out[i] = b2c[(unsigned)((key[bit >> 6] >> (bit & 63)) & 3)];
+  }
+}
+
 // libstdc++ std::_Hash_bytes, 64-bit variant (hash_bytes.cc), seed 0xc70f6907 from
 // bits/functional_hash.h; length = ceil(N/8) bytes of the bitset's little-endian words
 // (call site: src/MyHash.cpp:25).
@@ -157,12 +190,24 @@ double now_s() {
 extern "C" {
 
 void p3o_encode_fwd(const char* s, int k, uint64_t* key) {
+  if (k > 64) {
+    WideRoller w(k);
+    for (int i = 0; i < k; i++) w.push(s[i]);
+    std::memcpy(key, w.fwd, 8 * w.nw);
+    return;
+  }
   Roller r(k);
   for (int i = 0; i < k; i++) r.fwd = ((r.fwd << 2) | fwd_code(s[i])) & r.mask;
   store_key(r.fwd, k, key);
 }
 
 void p3o_encode_rc(const char* s, int k, uint64_t* key) {
+  if (k > 64) {
+    WideRoller w(k);
+    for (int i = 0; i < k; i++) w.push(s[i]);
+    std::memcpy(key, w.rc, 8 * w.nw);
+    return;
+  }
   u128 v = 0;
   const u128 mask = mask_of(k);
   for (int i = k - 1; i >= 0; i--) v = ((v << 2) | rc_code(s[i])) & mask;
@@ -171,6 +216,16 @@ void p3o_encode_rc(const char* s, int k, uint64_t* key) {
 
 void p3o_complement(const uint64_t* key, int k, uint64_t* out) {
   // src/BitCalc.cpp:35-45: base i (from the LSB end) becomes base k-1-i, complemented (3-b).
+  if (k > 64) {
+    uint64_t o[4] = {0, 0, 0, 0};
+    for (int i = 0; i < k; i++) {
+      const uint64_t b = (key[(2 * i) >> 6] >> ((2 * i) & 63)) & 3;
+      const int to = 2 * (k - 1 - i);
+      o[to >> 6] |= (3 - b) << (to & 63);
+    }
+    std::memcpy(out, o, 8 * nwords(k));
+    return;
+  }
   u128 v = load_key(key, k), o = 0;
   for (int i = 0; i < k; i++) {
     unsigned b = (unsigned)((v >> (2 * i)) & 3);
@@ -180,12 +235,26 @@ void p3o_complement(const uint64_t* key, int k, uint64_t* out) {
 }
 
 void p3o_canonical(const uint64_t* fwd, const uint64_t* rc, int k, uint64_t* out) {
+  if (k > 64) {
+    const uint64_t* pick = fwd;
+    for (int t = nwords(k) - 1; t >= 0; t--)
+      if (fwd[t] != rc[t]) {
+        pick = fwd[t] < rc[t] ? fwd : rc;
+        break;
+      }
+    std::memcpy(out, pick, 8 * nwords(k));
+    return;
+  }
   u128 f = load_key(fwd, k), r = load_key(rc, k);
   store_key(f <= r ? f : r, k, out);
 }
 
 void p3o_decode(const uint64_t* key, int k, char* out) {
   static const char b2c[4] = {'A', 'C', 'G', 'T'};
+  if (k > 64) {
+    decode_words(key, k, out);
+    return;
+  }
   u128 v = load_key(key, k);
   for (int i = 0; i < k; i++) out[i] = b2c[(unsigned)((v >> (2 * (k - 1 - i))) & 3)];
 }
@@ -290,10 +359,11 @@ int p3o_make_bf(const char* bases, const uint64_t* offsets, uint64_t n_reads, ui
                 int k, uint64_t m, int H, uint64_t* bloom_words,
                 char* seed_chars, uint64_t seed_cap, uint64_t* n_seeds,
                 uint64_t* n_inserted, int* count_overflow) {
-  if (k < 21 || k > 64 || m == 0) return 2;
+  if (k < 21 || k > 128 || m == 0) return 2;
   const uint64_t nw = (m + 63) / 64;
   std::memset(bloom_words, 0, nw * 8);
   std::set<std::string> seeds;
+  const bool wide = k > 64;
   uint64_t inserted = 0;
   int ovf = 0;
   std::vector<uint64_t> cov;
@@ -316,24 +386,27 @@ int p3o_make_bf(const char* bases, const uint64_t* offsets, uint64_t n_reads, ui
     // (b) sliding-window minimum, window k-21+1, src/MakeBloomFilter.cpp:62
     std::vector<uint64_t> rmq = rmq_ref_semantics(cov, k - 21 + 1);
     // (c,d) roll the large k-mer; insert canonical where rmq >= 2; first pass = seed (:64-85)
-    Roller rk(k);
+    Roller rk(wide ? 21 : k);
+    WideRoller wk(wide ? k : 65);
     bool seeded = false;
     for (uint64_t i = 0; i < L; i++) {
-      rk.push(s[i]);
+      if (wide) wk.push(s[i]);
+      else rk.push(s[i]);
       if (i + 1 < (uint64_t)k) continue;
       const uint64_t idx = i + 1 - k;
       if (rmq[idx] >= 2) {
-        uint64_t kw[2];
-        store_key(rk.canon(), k, kw);
-        if (nwords(k) == 1) kw[1] = 0;
+        uint64_t kw[4] = {0, 0, 0, 0};
+        if (wide) std::memcpy(kw, wk.canon(), 8 * wk.nw);
+        else store_key(rk.canon(), k, kw);
         uint64_t h1, h2;
         double_hash(kw, k, &h1, &h2);
         p3o_probe_positions(h1, h2, m, H, pos.data());
         for (int n = 0; n < H; n++) bloom_words[pos[n] >> 6] |= 1ULL << (pos[n] & 63);
         inserted++;
         if (!seeded) {
-          uint64_t fw[2];
-          store_key(rk.fwd, k, fw);
+          uint64_t fw[4] = {0, 0, 0, 0};
+          if (wide) std::memcpy(fw, wk.fwd, 8 * wk.nw);
+          else store_key(rk.fwd, k, fw);
           std::string sd(k, 'A');
           p3o_decode(fw, k, &sd[0]);  // GetStringKmer(kmer_Fw): unknown characters read back as 'A'
           seeds.insert(sd);
@@ -360,7 +433,8 @@ void p3o_bloom_query(const uint64_t* bloom_words, uint64_t m, int H, const uint6
   const int nw = nwords(k);
   std::vector<uint64_t> pos(H > 0 ? H : 1);
   for (uint64_t i = 0; i < n; i++) {
-    uint64_t kw[2] = {keys[i * nw], nw == 2 ? keys[i * nw + 1] : 0};
+    uint64_t kw[4] = {0, 0, 0, 0};
+    for (int t = 0; t < nw; t++) kw[t] = keys[i * nw + t];
     uint64_t h1, h2;
     double_hash(kw, k, &h1, &h2);
     p3o_probe_positions(h1, h2, m, H, pos.data());

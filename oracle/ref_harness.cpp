@@ -36,8 +36,9 @@
 
 namespace {
 
-// every supported large-k (1- and 2-word keys).  X(k)
+// every supported large-k (1- and 2-word keys, and a few of the 3- and 4-word ones incl. the reference's own 101).  X(k)
 #define P3REF_KLIST(X) \
+  X(65) X(80) X(96) X(97) X(101) X(127) X(128) \
   X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) \
   X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) \
   X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)

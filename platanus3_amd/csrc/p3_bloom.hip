@@ -514,6 +514,74 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
   return P3_OK;
 }
 
+
+// Bloom stage for keys of three and four words (65 <= k <= 128, p3_kernels_wide.h): the gate as for the short keys,
+// then one direct insert per passing window and the per-read seeds.  No k-mer partition, no replay hints (every pass
+// takes the careful path), no seed set on the device (p3_export_seeds sorts on the host).
+template <int NW>
+int do_bloom_wide(p3_ctx* c, u32 k, u64 m, u32 H) {
+  int rc;
+  const u64 nwa = c->n_words + P3_PAD_WORDS;
+  const u64 bwords = (m + 63) / 64;
+  const u64 bwords_padded = (bwords + c->n_ranks - 1) / c->n_ranks * c->n_ranks;
+  if ((rc = ensure(c, c->S, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->P, nwa * 4))) return rc;
+  if ((rc = ensure(c, c->bloom, bwords_padded * 8))) return rc;
+  if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->seed_valid, c->n_reads + 1))) return rc;
+  u64* st = (u64*)c->dstats.p;
+  // (position chunks: the count stage assembled S chunk by chunk over the whole stream)
+  const bool have_s = c->chunks > 1 || (c->count_mode == 2 && c->gate_mode == 2 && c->s_ready);
+  if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  if (have_s) {
+  } else if (c->count_mode == 2) {
+    LAUNCH(c, "k_gate_regions", k_gate_regions, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (const u32*)c->solid.p, (c->n_ranks > 1 ? c->xbits : 0) + c->sbits, c->rs_log2,
+           (u32*)c->S.p);
+  } else {
+    LAUNCH(c, "k_gate_direct", k_gate_direct, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, c->n_words, (const u64*)c->tkeys.p, (const u64*)c->tcounts.p, c->cap - 1, (u32*)c->S.p);
+  }
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+  const ModM mm = make_modm(m);
+  LAUNCH(c, "k_wide_bloom", (k_wide_bloom<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p, (u32*)c->P.p, st + 8);
+  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+  LAUNCH(c, "k_wide_seeds", (k_wide_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
+         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  c->seedset_ready = false;
+  HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+  u64 h[3] = {0, 0, 0}, count_flag = 0;
+  HIPCHK(c, hipMemcpyAsync(h, st + 8, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&count_flag, st + 26, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (count_flag) {
+    // the return path's non-solid-window partition overflowed its estimated capacity (the count stage does not
+    // synchronise for it): S lacks zeros -- count again at the next level, as do_bloom_t does
+    est_overflowed(c);
+    c->counted = false;
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded in the count stage's return path");
+  }
+  c->bstats.n_windows_k = h[0];
+  c->bstats.n_passing = h[1];
+  c->bstats.n_seed_reads = h[2];
+  c->n_distinct_k = 0;  // (not counted in this form)
+  c->bloom_mode = 4;
+  c->k = k;
+  c->m = m;
+  c->H = H;
+  c->bloomed = true;
+  c->graphed = false;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->tm.ms_gate = ms;
+  if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) c->tm.ms_bloom = ms;
+  if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->tm.ms_seeds = ms;
+  return P3_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -530,6 +598,8 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
                 (unsigned long long)c->cstats.max_count);
   HIPCHK(c, hipSetDevice(c->device));
   auto bloom_once = [&]() {
+    if (nw_of(k) == 3) return do_bloom_wide<3>(c, k, m_bits, H);
+    if (nw_of(k) == 4) return do_bloom_wide<4>(c, k, m_bits, H);
     if (c->chunks > 1) return nw_of(k) == 1 ? bloom_chunked<1>(c, k, m_bits, H) : bloom_chunked<2>(c, k, m_bits, H);
     return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
   };
@@ -601,23 +671,24 @@ int p3_export_seeds(p3_ctx* c, uint64_t* fwd_keys, uint64_t cap, uint64_t* n) {
     HIPCHK(c, hipMemcpy(h.data(), c->seeds.p, h.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(hv.data(), c->seed_valid.p, hv.size(), hipMemcpyDeviceToHost));
   }
-  // std::set<std::string> semantics: sort + unique.  String order == numeric order of the key.
-  std::vector<std::pair<u64, u64>> v;  // (hi, lo)
+  // std::set<std::string> semantics: sort + unique.  String order == numeric order of the key (most significant word
+  // first: word nw-1 ... word 0).
+  typedef std::array<u64, 4> SeedKey;
+  std::vector<SeedKey> v;
   v.reserve(c->n_reads);
   for (u64 r = 0; r < c->n_reads; r++) {
     if (!hv[r]) continue;
-    u64 lo = h[r * nw], hi = nw == 2 ? h[r * nw + 1] : 0;
-    v.push_back({hi, lo});
+    SeedKey kk = {0, 0, 0, 0};
+    for (int j = 0; j < nw; j++) kk[j] = h[r * nw + (nw - 1 - j)];  // kk[0] is compared first: the top word
+    v.push_back(kk);
   }
   std::sort(v.begin(), v.end());
   v.erase(std::unique(v.begin(), v.end()), v.end());
   *n = v.size();
   if (cap < v.size()) return fail(c, P3_ECAPACITY, "need %zu seed slots", v.size());
   if (v.size() && !fwd_keys) return fail(c, P3_EBADARG, "null output");
-  for (size_t i = 0; i < v.size(); i++) {
-    fwd_keys[i * nw] = v[i].second;
-    if (nw == 2) fwd_keys[i * nw + 1] = v[i].first;
-  }
+  for (size_t i = 0; i < v.size(); i++)
+    for (int j = 0; j < nw; j++) fwd_keys[i * nw + (nw - 1 - j)] = v[i][j];
   return P3_OK;
 }
 
@@ -641,6 +712,12 @@ int p3_bloom_query(p3_ctx* c, const uint64_t* keys, uint64_t n, uint8_t* out) {
     if (nw == 1)
       hipLaunchKernelGGL((k_bloom_query<1>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
                          c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
+    else if (nw == 3)
+      hipLaunchKernelGGL((k_wide_query<3>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
+                         c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
+    else if (nw == 4)
+      hipLaunchKernelGGL((k_wide_query<4>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
+                         c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
     else
       hipLaunchKernelGGL((k_bloom_query<2>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
                          c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
@@ -662,7 +739,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
   // (overflow flags are checked there; on any surprise the pass is simply repeated the careful way).
   const bool can_spec = c->ad.hint_valid && c->hint_epoch == c->reads_epoch && c->hint_k == k && c->hint_m == m_bits &&
                         c->hint_H == H && c->n_ranks == 1 && c->count_mode_opt != 1 && c->gate_mode_opt != 1 &&
-                        c->bloom_mode_opt != 1 && !c->dbg_opt;
+                        c->bloom_mode_opt != 1 && !c->dbg_opt && nw_of(k) <= 2;
   if (can_spec) {
     HIPCHK(c, hipSetDevice(c->device));
     c->spec = true;

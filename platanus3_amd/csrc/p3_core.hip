@@ -183,8 +183,9 @@ int do_pack(p3_ctx* c) {
   return P3_OK;
 }
 
+// count, gate, Bloom vector and seeds: k in 21..128 (one to four key words); the de Bruijn stage: k <= 64 (p3_graph.hip)
 int check_k(p3_ctx* c, u32 k) {
-  if (k < 21 || k > 64) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,64]", k);
+  if (k < 21 || k > 128) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,128]", k);
   return P3_OK;
 }
 

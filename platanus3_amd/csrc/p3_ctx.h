@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -31,6 +32,7 @@
 #include "p3_kernels_retgate.h"
 #include "p3_kernels_sk.h"
 #include "p3_kernels_seedset.h"
+#include "p3_kernels_wide.h"
 
 struct KStat {
   std::string name;

@@ -133,6 +133,7 @@ int p3_build_graph(p3_ctx* c) {
   if (!c) return P3_EBADARG;
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
+  if (nw_of(c->k) > 2) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes k <= 64 (k=%u: Bloom vector and seeds only)", c->k);
   HIPCHK(c, hipSetDevice(c->device));
   return nw_of(c->k) == 1 ? build_graph_t<1>(c) : build_graph_t<2>(c);
 }

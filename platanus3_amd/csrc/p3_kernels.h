@@ -18,7 +18,7 @@
 #include "p3_device.h"
 
 #define P3_EMPTY_KEY (~0ULL)
-#define P3_PAD_WORDS 4  // stream words past the last base, so every lane may read w..w+3
+#define P3_PAD_WORDS 8  // stream words past the last base, so every lane may read w..w+5 (wide keys: a window spans 5 words)
 
 // the 32 2-bit groups of x in reverse order (group i <-> group 31 - i), bits inside a group kept
 __device__ __forceinline__ u64 sk_pairs_reversed(u64 x) {

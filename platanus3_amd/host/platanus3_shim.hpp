@@ -12,8 +12,8 @@
 // the classes are re-declared with the reference's member names and filled from the flat results of the ABI.
 //
 // Differences a maintainer should know:
-//   * k must be in [21,64]; unsupported k throws std::invalid_argument (the reference's Assemble_k silently
-//     returns 1, src/Assemble.cpp:51-52);
+//   * CountShortKmer / MakeBF take k in [21,128] (the reference's k = 101 included), the DeBruijnGraph stage k <= 64;
+//     unsupported k throws (the reference's Assemble_k silently returns 1, src/Assemble.cpp:51-52);
 //   * materialising the STL containers (17.7 M unordered_map inserts at config #2) costs seconds of host
 //     time -- callers that can consume flat arrays should use the C ABI directly;
 //   * BF<Key>::possiblyContains / add stay usable on the host object (the unchanged DeBruijnGraph code calls
@@ -392,7 +392,7 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
                         std::set<std::string>* seed_kmer, Logging& logging) {
   (void)logging;
   if (LARGE_BITSET().size() != (size_t)(2 * kmer_length)) throw std::invalid_argument("MakeBF: bitset width != 2k");
-  if (kmer_length < 21 || kmer_length > 64) throw std::invalid_argument("MakeBF: k outside [21,64]");
+  if (kmer_length < 21 || kmer_length > 128) throw std::invalid_argument("MakeBF: k outside [21,128]");
   p3shim::Session& s = p3shim::Session::get();
   p3_ctx* ctx = s.context();
   // The device-resident count table is reused when CountShortKmer was just run on the same ReadSet; KC itself
