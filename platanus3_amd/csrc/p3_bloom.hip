@@ -58,9 +58,21 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   u64* st = (u64*)c->dstats.p;
   const bool have_s = c->count_mode == 2 && c->gate_mode == 2 && c->s_ready;
   if (!have_s) HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
-  if (c->kphase != 2) HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
-  if (!c->chunk_acc) HIPCHK(c, hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
+  // Fills are launches too (~5 us each): the replay of a pass (spec) skips those whose target the pass's own kernels
+  // write in full -- P by the k-mer scatter that evaluates the gate (estimated capacities, one partition), the vector by
+  // k_bloom_slices (zero_bloom below, called by the forms that OR into it) -- and the statistics words part_local zeroed.
+  const bool p_written_whole = c->spec && c->ad.est_ok && c->sizing_opt != 1 && c->kphase == 0 && c->chunks <= 1;
+  if (c->kphase != 2 && !p_written_whole) HIPCHK(c, hipMemsetAsync(c->P.p, 0, nwa * 4, c->stream));
+  bool bloom_zeroed = c->chunk_acc;  // (position chunks accumulate into a vector bloom_chunked zeroed)
+  auto zero_bloom = [&]() -> hipError_t {
+    if (bloom_zeroed) return hipSuccess;
+    bloom_zeroed = true;
+    return hipMemsetAsync(c->bloom.p, 0, bwords_padded * 8, c->stream);
+  };
+  if (!c->spec) {
+    HIPCHK(c, zero_bloom());
+    HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
+  }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (have_s || c->kphase == 2) {
     // S was assembled by the count stage's return path (kphase 2: the gate has been applied chunk by chunk)
@@ -334,12 +346,14 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                        (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
                        (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
           }
+          if (c->n_ranks > 1 || bwords_padded != bwords) HIPCHK(c, zero_bloom());  // (the slices cover words below bwords)
           LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
                      (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
                      (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase);
         }
         c->bloom_mode = 3;
       } else {
+        HIPCHK(c, zero_bloom());
         LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H,
                (u32*)c->bloom.p);
         c->bloom_mode = 2;
@@ -353,6 +367,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (!use_dedup && c->kphase == 2) return fail(c, P3_ECAPACITY, "global k-mer dedup overflowed at every split");
   if (!use_dedup && c->kphase == 1) return fail(c, P3_ECAPACITY, "no deduplicated keys to collect");
   if (!use_dedup) {
+    HIPCHK(c, zero_bloom());
     LAUNCH(c, "k_bloom_direct", (k_bloom_direct<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p,
            (const u64*)c->rcw.p, (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p,
            (u32*)c->P.p, st + 8);

@@ -127,14 +127,35 @@ double active_wgs(u64 n_words) {
   return (double)(a ? a : 1);
 }
 
+// Fixed-stride segment offsets (entry i = i * segcap).  A pass uses four different strides (count, return path, k-mers,
+// probes) and the next pass the same four again, so the tables are KEPT: c->seg_off is swapped with one of four cached
+// tables instead of being rewritten (4 launches and 4 MB of writes per pass otherwise).  do_scan, the only other writer
+// of c->seg_off, marks it as holding no fixed-stride table.
 int fixed_segoff(p3_ctx* c, u32 segcap) {
+  int rc;
+  if (c->seg_off.p && c->segoff_holds == segcap) return P3_OK;
+  for (int i = 0; i < 4; i++)
+    if (c->segoff_cache[i].p && c->segoff_cache_cap[i] == segcap) {
+      std::swap(c->seg_off, c->segoff_cache[i]);
+      std::swap(c->segoff_holds, c->segoff_cache_cap[i]);
+      return P3_OK;
+    }
+  if (c->seg_off.p && c->segoff_holds) {  // park the current table, take over the victim's memory
+    const int v = (int)(c->segoff_next++ & 3u);
+    std::swap(c->seg_off, c->segoff_cache[v]);
+    c->segoff_cache_cap[v] = c->segoff_holds;
+  }
+  c->segoff_holds = 0;
+  if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off.p, segcap);
+  c->segoff_holds = segcap;
   return P3_OK;
 }
 
 // exact segment offsets from the (bucket, workgroup) histogram; totals -> st_totals[0..2]
 int do_scan(p3_ctx* c, u64* st_totals) {
   int rc;
+  c->segoff_holds = 0;
   if ((rc = ensure(c, c->scan_tmp, (size_t)P3_NB * 4))) return rc;
   LAUNCH(c, "k_part_scan", k_part_scan_rows, P3_NB / 4, 256, (const u32*)c->ghist.p, (u32*)c->seg_off.p,
          (u32*)c->bucket_count.p, (u32*)c->scan_tmp.p);
@@ -190,8 +211,7 @@ int part_local(p3_ctx* c, bool with_pos) {
     if ((rc = fixed_segoff(c, segcap))) return rc;
     LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds8, (const u64*)c->fw.p,
                (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p, (u64*)c->part8.p,
-               (EstSeg{segcap, (u32*)c->ghist.p, st + 26}));
-    LAUNCH(c, "k_sum_u32", k_sum_u32, 256, 256, (const u32*)c->ghist.p, P3_NB * P3_NWG, st + 5);
+               (EstSeg{segcap, (u32*)c->ghist.p, st + 26}), st + 5);
   } else {
     LAUNCH(c, "k_part_hist", k_part_hist, P3_NWG, P3_PART_THREADS, (const u64*)c->fw.p, (const u64*)c->rcw.p,
            (const u32*)c->endm.p, c->n_words, (u32*)c->ghist.p);
@@ -199,7 +219,7 @@ int part_local(p3_ctx* c, bool with_pos) {
     if (with_pos) {
       LAUNCH_LDS(c, "k_part_scatter_pos", k_part_scatter_pos, P3_NWG, P3_PART_THREADS, lds8, (const u64*)c->fw.p,
                  (const u64*)c->rcw.p, (const u32*)c->endm.p, c->n_words, (const u32*)c->seg_off.p,
-                 (u64*)c->part8.p, (EstSeg{0, nullptr, nullptr}));
+                 (u64*)c->part8.p, (EstSeg{0, nullptr, nullptr}), (u64*)nullptr);
     } else {
       const size_t lds = ((size_t)P3_NB * P3_CAP + 3 * P3_NB) * 4;
       LAUNCH_LDS(c, "k_part_scatter", k_part_scatter, P3_NWG, P3_PART_THREADS, lds, (const u64*)c->fw.p,
@@ -262,7 +282,8 @@ int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
   if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
   c->k2ext_h[0] = out_cap;
   HIPCHK(c, hipMemcpyAsync((u64*)c->dstats.p + 30, c->k2ext_h, 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync((u64*)c->sing_cursor.p + P3_MAX_RANKS, 0, 8 * P3_MAX_RANKS, c->stream));
+  // both halves at once: the per-source cursors (first half) and the list starts (second half)
+  HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * 2 * P3_MAX_RANKS, c->stream));
   if (sroff && n)
     HIPCHK(c, hipMemcpyAsync((u64*)c->sing_cursor.p + P3_MAX_RANKS, sroff, 8 * n, hipMemcpyDeviceToDevice, c->stream));
   return P3_OK;
@@ -311,14 +332,15 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if ((rc = ensure(c, c->sb_info, (size_t)nsb * 16))) return rc;
   if ((rc = set_k2ext(c, maxd, c->n_ranks > 1 ? c->rx_roff.p : nullptr, c->n_ranks))) return rc;
   u64* st = (u64*)c->dstats.p;
-  HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
+  if (!c->spec) {  // (replay: part_local has just zeroed every statistics word and nothing wrote these since)
+    HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
+  }
   const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
   if (c->part_sk) {
     if (sbits < c->sk_fbits) return fail(c, P3_EHIP, "run records: split %u below the scattered fine buckets %u", sbits, c->sk_fbits);
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
     const u32 nwaves = (u32)c->sk_waves_opt;
     const size_t lds = ((size_t)8 << ts_log2) + nwaves * SK_WAVE_LDS + P3_NWG * 4 + 64;
     if (lds > 160u * 1024u) return fail(c, P3_EBADARG, "run-record count: %zu bytes of LDS (sk_ts_log2 / sk_waves)", lds);
@@ -329,8 +351,6 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   } else if (c->part_pos) {
     if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;  // (src|slot|pos) per first instance
     if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
-    if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
     if (xbits > 0 && c->n_ranks > 1 && (1u << xbits) >= c->n_ranks) {
       LAUNCH_K2(true, nsb, 1024, lds, (const u64*)kpart,
@@ -524,7 +544,8 @@ int solid_bits(p3_ctx* c, const u32* d_positions, const u64* d_n_pos, u64 n_pos_
   const u32 ns = (u32)((n_bits + ((1ull << slice_log2) - 1)) >> slice_log2);
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   u64* st = (u64*)c->dstats.p;
-  HIPCHK(c, hipMemsetAsync(c->S.p, 0, nwa * 4, c->stream));
+  // (k_solid_slices writes every word below n_words: only the padding needs zeroing)
+  HIPCHK(c, hipMemsetAsync((u32*)c->S.p + c->n_words, 0, P3_PAD_WORDS * 4, c->stream));
   const size_t lds_sc = (size_t)P3_STAGE_WORDS * 4;
   // estimated mode needs the number of positions (or last pass's) on the host to size the segments
   const u64 n_est = c->spec ? c->hint_nsing : n_pos_bound;

@@ -79,6 +79,9 @@ struct p3_ctx {
   int ts_log2_opt = P3_TS_LOG2_MAX;
   u32 sbits = 1, rs_log2 = 6;
   DevBuf ghist, seg_off, bucket_count, part, sb_info, solid;
+  DevBuf segoff_cache[4];          // fixed-stride offset tables kept from earlier stages / passes (fixed_segoff)
+  u32 segoff_cache_cap[4] = {0, 0, 0, 0};
+  u32 segoff_holds = 0, segoff_next = 0;  // stride of the table in seg_off (0 = exact offsets or nothing)
   bool ccounts_u32 = false;
   int bloom_mode_opt = 0;   // 0 auto, 1 direct (one insert per window), 2 dedup (one insert per distinct k-mer)
   int bloom_mode = 0;

@@ -25,14 +25,15 @@ static __global__ void __launch_bounds__(256) k_fixed_segoff(u32* __restrict__ s
 static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                                       const u32* __restrict__ endm, u64 n_words,
                                                                       const u32* __restrict__ seg_off,
-                                                                      u64* __restrict__ part, EstSeg est) {
+                                                                      u64* __restrict__ part, EstSeg est,
+                                                                      u64* __restrict__ n_windows) {
   constexpr int RW = 4;
   extern __shared__ __align__(16) u32 lds[];
   const StageLds stg = stage_layout(lds);
   stage_init(stg, seg_off, est);
   u64 begin, end;
   part_word_range(n_words, blockIdx.x, begin, end);
-  u32 vbits = 0;
+  u32 vbits = 0, n_valid = 0;
   u64 base = begin;
   int round = 32 / RW;  // "tile exhausted": the first call loads the first tile
   bool first = true;
@@ -53,6 +54,7 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(con
         L = load_lane_words(fw, rcw, endm, w);
         kr.init(21, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
         vbits = ~win_or32(L.Elo, L.Ehi, 20);  // window p is valid <=> no read end in [p, p+20)
+        n_valid += __popc(vbits);
       }
     }
     pend = 0;
@@ -73,6 +75,15 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(con
     round++;
     return true;
   });
+  if (n_windows) {  // valid windows of this workgroup -> one global atomic (the stage is drained: its counters are free)
+    __syncthreads();
+    if (threadIdx.x == 0) stg.cnt[0] = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_down(n_valid, off, 64);
+    if ((threadIdx.x & 63) == 0 && n_valid) atomicAdd(&stg.cnt[0], n_valid);
+    __syncthreads();
+    if (threadIdx.x == 0 && stg.cnt[0]) atomicAdd((unsigned long long*)n_windows, (unsigned long long)stg.cnt[0]);
+  }
 }
 
 // ---- generic partition of plain u32 values by (v >> shift): histogram + scatter of (v & mask) ---------------------
