@@ -183,7 +183,7 @@ int do_pack(p3_ctx* c) {
   return P3_OK;
 }
 
-// count, gate, Bloom vector and seeds: k in 21..128 (one to four key words); the de Bruijn stage: k <= 64 (p3_graph.hip)
+// every stage takes k in 21..128 (one to four key words)
 int check_k(p3_ctx* c, u32 k) {
   if (k < 21 || k > 128) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,128]", k);
   return P3_OK;
@@ -238,7 +238,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
                     &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps, &c->unk_flag,
                     &c->seed_part, &c->seed_hist, &c->seed_set, &c->seed_ucount, &c->seed_flag, &c->g_jtcov, &c->xc_buf,
-                    &c->xg_buf, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3]};
+                    &c->xg_buf, &c->g_k2, &c->g_k3, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3]};
   for (DevBuf* b : bufs) release(*b);
   free_outgrown(c);
   for (auto& ev : c->ev)

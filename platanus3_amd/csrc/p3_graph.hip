@@ -14,13 +14,9 @@ int build_graph_t(p3_ctx* c) {
   p.k = k;
   p.H = c->H;
   p.mm = make_modm(c->m);
-  if (NW == 1) {
-    p.mask_lo = (2 * k == 64) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    p.mask_hi = 0;
-  } else {
-    p.mask_lo = ~0ULL;
-    p.mask_hi = (2 * k == 128) ? ~0ULL : ((1ULL << (2 * k - 64)) - 1);
-  }
+  p.top_bits = 2 * k - 64 * (NW - 1);  // 2 .. 64
+  p.mask_top = p.top_bits == 64 ? ~0ULL : ((1ULL << p.top_bits) - 1);
+  DevBuf* kbuf[4] = {&c->g_klo, &c->g_khi, &c->g_k2, &c->g_k3};
   if ((rc = ensure(c, c->g_ctr, 16 * 8))) return rc;
   u64* ctr = (u64*)c->g_ctr.p;
   // table capacity: a few times the number of distinct inserted k-mers (false-positive neighbours add nodes)
@@ -41,8 +37,8 @@ int build_graph_t(p3_ctx* c) {
     c->g_cap = cap;
     const u64 node_limit = cap / 2 + cap / 8;  // 62 % load at most
     const u64 fcap = 8 * node_limit + 64;       // every inserted node appends at most 8 neighbours
-    if ((rc = ensure(c, c->g_klo, cap * 8))) return rc;
-    if (NW == 2 && (rc = ensure(c, c->g_khi, cap * 8))) return rc;
+    for (int j = 0; j < NW; j++)
+      if ((rc = ensure(c, *kbuf[j], cap * 8))) return rc;
     if ((rc = ensure(c, c->g_info, cap * 4))) return rc;
     if ((rc = ensure(c, c->g_nid, cap * 4))) return rc;
     if ((rc = ensure(c, c->g_f0, fcap * 8 * NW))) return rc;
@@ -51,7 +47,7 @@ int build_graph_t(p3_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->g_info.p, 0, cap * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->g_nid.p, 0, cap * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(ctr, 0, 16 * 8, c->stream));
-    DbgTab t{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
+    DbgTab t{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
     // level 0: the per-read seed keys (MakeDBG iterates the seed set, :96-105)
     const u64* fin = (const u64*)c->seeds.p;
     const uint8_t* fvalid = (const uint8_t*)c->seed_valid.p;
@@ -79,7 +75,7 @@ int build_graph_t(p3_ctx* c) {
     cap <<= 2;
   }
   const u64 n_nodes = hc[1];
-  DbgTab t{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
+  DbgTab t{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
   LAUNCH(c, "k_dbg_classify", (k_dbg_classify<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, ctr);
   // runs: pass 0 registers them, the host lays the sequences out, pass 1 writes them
   if ((rc = ensure(c, c->g_runs, (n_nodes / 2 + 16) * sizeof(DbgRun)))) return rc;
@@ -133,9 +129,13 @@ int p3_build_graph(p3_ctx* c) {
   if (!c) return P3_EBADARG;
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
-  if (nw_of(c->k) > 2) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes k <= 64 (k=%u: Bloom vector and seeds only)", c->k);
   HIPCHK(c, hipSetDevice(c->device));
-  return nw_of(c->k) == 1 ? build_graph_t<1>(c) : build_graph_t<2>(c);
+  switch (nw_of(c->k)) {
+    case 1: return build_graph_t<1>(c);
+    case 2: return build_graph_t<2>(c);
+    case 3: return build_graph_t<3>(c);
+    default: return build_graph_t<4>(c);
+  }
 }
 
 int p3_get_graph_stats(p3_ctx* c, p3_graph_stats* out) {

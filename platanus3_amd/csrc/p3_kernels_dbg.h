@@ -13,8 +13,11 @@
 //   k_dbg_edges     the L lines of PrintGraph (:468-543) as flat records
 //
 // Node table: open addressing on the canonical key; info word = neighbour masks + flags; nid = junction / straight id.
+// Keys are DKey<NW>, NW = 1 .. 4 words (k <= 128): one template for every width (round 2; the one- and two-word
+// instances compute what the former (lo, hi) code did).
 #pragma once
 #include "p3_kernels_retgate.h"
+#include "p3_kernels_wide.h"
 
 #define DBG_FULL (1u << 8)
 #define DBG_JUNCTION (1u << 9)
@@ -28,9 +31,14 @@
 #define DBG_BUSY (1u << 30)
 #define DBG_NOSLOT (~0ULL)
 
+// A key = NW 64-bit words, word 0 least significant (1 <= NW <= 4: k <= 128)
+template <int NW>
+struct DKey {
+  u64 w[NW];
+};
+
 struct DbgTab {
-  u64* klo;
-  u64* khi;   // NW == 2 only
+  u64* kw[4];  // key words, one array per word (kw[1..3] only for NW >= 2, 3, 4)
   u32* info;
   u32* nid;
   u64 cap_mask;
@@ -39,7 +47,8 @@ struct DbgTab {
 struct DbgParams {
   u32 k, H;
   ModM mm;
-  u64 mask_lo, mask_hi;  // 2k-bit key mask
+  u64 mask_top;   // mask of the top key word
+  u32 top_bits;   // 2k - 64 (NW - 1)
 };
 
 // ---- key arithmetic ---------------------------------------------------------------------------------------------
@@ -50,56 +59,98 @@ __device__ __forceinline__ u64 rev2bit64(u64 x) {  // reverse the order of the 3
 }
 
 template <int NW>
-__device__ __forceinline__ void key_rc(u64 lo, u64 hi, u32 k, u64& olo, u64& ohi) {  // GetComplementKmer, src/BitCalc.cpp:35-45
-  if (NW == 1) {
-    olo = (~rev2bit64(lo)) >> (64 - 2 * k);
-    ohi = 0;
-  } else {
-    const u64 rhi = ~rev2bit64(lo), rlo = ~rev2bit64(hi);  // 128-bit group reversal = swap + reverse each word
-    const u32 sh = 128 - 2 * k;                             // 0..62
-    ohi = rhi >> sh;
-    olo = sh ? ((rlo >> sh) | (rhi << (64 - sh))) : rlo;
+__device__ __forceinline__ bool dkey_eq(const DKey<NW>& a, const DKey<NW>& b) {
+  bool e = true;
+#pragma unroll
+  for (int t = 0; t < NW; t++) e = e && a.w[t] == b.w[t];
+  return e;
+}
+template <int NW>
+__device__ __forceinline__ bool dkey_less(const DKey<NW>& a, const DKey<NW>& b) {  // numeric order, top word first
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int t = NW - 1; t >= 0; t--) {
+    if (!decided && a.w[t] != b.w[t]) {
+      lt = a.w[t] < b.w[t];
+      decided = true;
+    }
   }
+  return lt;
+}
+// 2-bit code at bit position `bit` (even) of the key
+template <int NW>
+__device__ __forceinline__ u32 dkey_code(const DKey<NW>& a, u32 bit) {
+  u64 word = a.w[0];
+#pragma unroll
+  for (int t = 1; t < NW; t++) word = ((bit >> 6) == (u32)t) ? a.w[t] : word;
+  return (u32)(word >> (bit & 63)) & 3u;
 }
 
 template <int NW>
-__device__ __forceinline__ bool key_canon(u64 lo, u64 hi, u32 k, u64& clo, u64& chi) {  // returns true if flipped
-  u64 rlo, rhi;
-  key_rc<NW>(lo, hi, k, rlo, rhi);
-  const bool keep = (NW == 1) ? (lo <= rlo) : (hi < rhi || (hi == rhi && lo <= rlo));
-  clo = keep ? lo : rlo;
-  chi = keep ? hi : rhi;
+__device__ __forceinline__ DKey<NW> key_rc(const DKey<NW>& a, const DbgParams& p) {  // GetComplementKmer, src/BitCalc.cpp:35-45
+  // complement + reversal of all 32 NW groups = word order swapped, groups of every word reversed; then down by the
+  // 64 NW - 2k unused bits
+  u64 r[NW];
+#pragma unroll
+  for (int t = 0; t < NW; t++) r[t] = ~rev2bit64(a.w[NW - 1 - t]);
+  const u32 sh = 64 - p.top_bits;  // 0..62
+  DKey<NW> o;
+#pragma unroll
+  for (int t = 0; t < NW; t++) {
+    const u64 up = (t + 1 < NW) ? r[t + 1] : 0;
+    o.w[t] = sh ? ((r[t] >> sh) | (up << (64 - sh))) : r[t];
+  }
+  return o;
+}
+
+template <int NW>
+__device__ __forceinline__ bool key_canon(const DKey<NW>& a, const DbgParams& p, DKey<NW>& c) {  // returns true if flipped
+  const DKey<NW> r = key_rc<NW>(a, p);
+  const bool keep = !dkey_less<NW>(r, a);  // a <= rc(a)
+#pragma unroll
+  for (int t = 0; t < NW; t++) c.w[t] = keep ? a.w[t] : r.w[t];
   return !keep;
 }
 
 template <int NW>
-__device__ __forceinline__ void key_left(u64 lo, u64 hi, u32 k, u32 b, u64& olo, u64& ohi) {  // (x>>2) | b<<(2k-2)
-  if (NW == 1) {
-    olo = (lo >> 2) | ((u64)b << (2 * k - 2));
-    ohi = 0;
+__device__ __forceinline__ DKey<NW> key_left(const DKey<NW>& a, const DbgParams& p, u32 b) {  // (x >> 2) | b << (2k - 2)
+  DKey<NW> o;
+#pragma unroll
+  for (int t = 0; t < NW - 1; t++) o.w[t] = (a.w[t] >> 2) | (a.w[t + 1] << 62);
+  o.w[NW - 1] = (a.w[NW - 1] >> 2) | ((u64)b << (p.top_bits - 2));
+  return o;
+}
+
+template <int NW>
+__device__ __forceinline__ DKey<NW> key_right(const DKey<NW>& a, const DbgParams& p, u32 b) {  // ((x << 2) | b) & mask
+  DKey<NW> o;
+#pragma unroll
+  for (int t = NW - 1; t > 0; t--) o.w[t] = (a.w[t] << 2) | (a.w[t - 1] >> 62);
+  o.w[0] = (a.w[0] << 2) | b;
+  o.w[NW - 1] &= p.mask_top;
+  return o;
+}
+
+// libstdc++ _Hash_bytes over ceil(2k/8) bytes of the key words + GetDoubleHash_64bit (any NW; the one- and two-word
+// forms of p3_device.h compute the same)
+template <int NW>
+__device__ __forceinline__ void dkey_double_hash(const DKey<NW>& key, u32 k, u64& o1, u64& o2) {
+  if constexpr (NW <= 2) {
+    double_hash_key<NW>(key.w[0], NW == 2 ? key.w[NW - 1] : 0, k, o1, o2);
   } else {
-    olo = (lo >> 2) | (hi << 62);
-    ohi = (hi >> 2) | ((u64)b << (2 * k - 2 - 64));
+    WKey<NW> wk;
+#pragma unroll
+    for (int t = 0; t < NW; t++) wk.w[t] = key.w[t];
+    wide_double_hash(wide_std_hash<NW>(wk, k), o1, o2);
   }
 }
 
 template <int NW>
-__device__ __forceinline__ void key_right(u64 lo, u64 hi, const DbgParams& p, u32 b, u64& olo, u64& ohi) {  // (x<<2)|b
-  if (NW == 1) {
-    olo = ((lo << 2) | b) & p.mask_lo;
-    ohi = 0;
-  } else {
-    ohi = ((hi << 2) | (lo >> 62)) & p.mask_hi;
-    olo = (lo << 2) | b;
-  }
-}
-
-template <int NW>
-__device__ __forceinline__ bool bloom_has(const u32* __restrict__ bloom, const DbgParams& p, u64 lo, u64 hi) {
-  u64 clo, chi;
-  key_canon<NW>(lo, hi, p.k, clo, chi);  // IsRecorded queries the canonical form (:320-322)
+__device__ __forceinline__ bool bloom_has(const u32* __restrict__ bloom, const DbgParams& p, const DKey<NW>& a) {
+  DKey<NW> c;
+  key_canon<NW>(a, p, c);  // IsRecorded queries the canonical form (:320-322)
   u64 h1, h2;
-  double_hash_key<NW>(clo, chi, p.k, h1, h2);
+  dkey_double_hash<NW>(c, p.k, h1, h2);
   Probe pr = probe_begin(h1, h2, p.mm);
   for (u32 n = 0; n < p.H; n++) {
     if (!((bloom[pr.r >> 5] >> (pr.r & 31)) & 1)) return false;
@@ -109,24 +160,35 @@ __device__ __forceinline__ bool bloom_has(const u32* __restrict__ bloom, const D
 }
 
 template <int NW>
-__device__ __forceinline__ u64 dbg_hash(u64 lo, u64 hi) {
-  return NW == 1 ? mix64(lo ^ 0xD6E8FEB86659FD93ULL) : mix64(lo ^ mix64(hi ^ 0xD6E8FEB86659FD93ULL));
+__device__ __forceinline__ u64 dbg_hash(const DKey<NW>& a) {
+  u64 h = 0xD6E8FEB86659FD93ULL;
+#pragma unroll
+  for (int t = NW - 1; t > 0; t--) h = mix64(a.w[t] ^ h);
+  return mix64(a.w[0] ^ h);
+}
+
+template <int NW>
+__device__ __forceinline__ DKey<NW> tab_key(const DbgTab& t, u64 slot) {
+  DKey<NW> o;
+#pragma unroll
+  for (int j = 0; j < NW; j++) o.w[j] = t.kw[j][slot];
+  return o;
 }
 
 // slot of a canonical key, or DBG_NOSLOT
 template <int NW>
-__device__ __forceinline__ u64 node_find(const DbgTab& t, u64 clo, u64 chi) {
-  u64 slot = dbg_hash<NW>(clo, chi) & t.cap_mask;
+__device__ __forceinline__ u64 node_find(const DbgTab& t, const DKey<NW>& c) {
+  u64 slot = dbg_hash<NW>(c) & t.cap_mask;
   for (u64 probes = 0; probes <= t.cap_mask; probes++) {
     if (NW == 1) {
-      const u64 cur = t.klo[slot];
-      if (cur == clo) return slot;
+      const u64 cur = t.kw[0][slot];
+      if (cur == c.w[0]) return slot;
       if (cur == ~0ULL) return DBG_NOSLOT;
     } else {
       const u32 st = __hip_atomic_load(&t.info[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if (st == 0) return DBG_NOSLOT;
       if (st & DBG_KEYED) {
-        if (t.klo[slot] == clo && t.khi[slot] == chi) return slot;
+        if (dkey_eq<NW>(tab_key<NW>(t, slot), c)) return slot;
       } else {
         probes--;  // being written by another lane: look again (the writer never waits on us)
         continue;
@@ -139,17 +201,17 @@ __device__ __forceinline__ u64 node_find(const DbgTab& t, u64 clo, u64 chi) {
 
 // returns true when THIS call inserted the key
 template <int NW>
-__device__ __forceinline__ bool node_insert(const DbgTab& t, u64 clo, u64 chi, u64& out_slot) {
-  u64 slot = dbg_hash<NW>(clo, chi) & t.cap_mask;
+__device__ __forceinline__ bool node_insert(const DbgTab& t, const DKey<NW>& c, u64& out_slot) {
+  u64 slot = dbg_hash<NW>(c) & t.cap_mask;
   for (u64 probes = 0; probes <= t.cap_mask; probes++) {
     if (NW == 1) {
-      u64 cur = t.klo[slot];
-      if (cur == ~0ULL) cur = atomicCAS((unsigned long long*)&t.klo[slot], ~0ULL, (unsigned long long)clo);
+      u64 cur = t.kw[0][slot];
+      if (cur == ~0ULL) cur = atomicCAS((unsigned long long*)&t.kw[0][slot], ~0ULL, (unsigned long long)c.w[0]);
       if (cur == ~0ULL) {
         out_slot = slot;
         return true;
       }
-      if (cur == clo) {
+      if (cur == c.w[0]) {
         out_slot = slot;
         return false;
       }
@@ -157,8 +219,8 @@ __device__ __forceinline__ bool node_insert(const DbgTab& t, u64 clo, u64 chi, u
       const u32 st = __hip_atomic_load(&t.info[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if (st == 0) {
         if (atomicCAS(&t.info[slot], 0u, DBG_BUSY) == 0u) {
-          t.klo[slot] = clo;
-          t.khi[slot] = chi;
+#pragma unroll
+          for (int j = 0; j < NW; j++) t.kw[j][slot] = c.w[j];
           __hip_atomic_store(&t.info[slot], DBG_BUSY | DBG_KEYED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           out_slot = slot;
           return true;
@@ -170,7 +232,7 @@ __device__ __forceinline__ bool node_insert(const DbgTab& t, u64 clo, u64 chi, u
         probes--;
         continue;
       }
-      if (t.klo[slot] == clo && t.khi[slot] == chi) {
+      if (dkey_eq<NW>(tab_key<NW>(t, slot), c)) {
         out_slot = slot;
         return false;
       }
@@ -191,24 +253,22 @@ static __global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_in) return;
   if (fin_valid && !fin_valid[i]) return;
-  const u64 lo = fin[i * NW], hi = (NW == 2) ? fin[i * NW + 1] : 0;
-  u64 clo, chi, slot;
-  key_canon<NW>(lo, hi, p.k, clo, chi);
-  if (!node_insert<NW>(t, clo, chi, slot)) {
+  DKey<NW> key, c;
+#pragma unroll
+  for (int j = 0; j < NW; j++) key.w[j] = fin[i * NW + j];
+  u64 slot;
+  key_canon<NW>(key, p, c);
+  if (!node_insert<NW>(t, c, slot)) {
     if (slot == DBG_NOSLOT) ctr[2] = 1;
     return;  // already a node (IsVisited, :159)
   }
   if (atomicAdd((unsigned long long*)&ctr[1], 1ULL) >= node_limit) ctr[2] = 1;
-  u32 lmask = 0, rmask = 0;
-  u64 nlo[8], nhi[8];
+  u32 all = 0;  // bits 0..3: left neighbours by base, 4..7: right neighbours
 #pragma unroll
   for (u32 b = 0; b < 4; b++) {
-    key_left<NW>(clo, chi, p.k, b, nlo[b], nhi[b]);
-    if (bloom_has<NW>(bloom, p, nlo[b], nhi[b])) lmask |= 1u << b;
-    key_right<NW>(clo, chi, p, b, nlo[4 + b], nhi[4 + b]);
-    if (bloom_has<NW>(bloom, p, nlo[4 + b], nhi[4 + b])) rmask |= 1u << b;
+    if (bloom_has<NW>(bloom, p, key_left<NW>(c, p, b))) all |= 1u << b;
+    if (bloom_has<NW>(bloom, p, key_right<NW>(c, p, b))) all |= 16u << b;
   }
-  const u32 all = lmask | (rmask << 4);
   const u32 base_info = DBG_FULL | DBG_KEYED | all;
   __hip_atomic_store(&t.info[slot], base_info, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   const u32 n_nb = __popc(all);
@@ -222,8 +282,9 @@ static __global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict
 #pragma unroll
     for (u32 j = 0; j < 8; j++) {
       if (all & (1u << j)) {
-        fout[(at + w) * NW] = nlo[j];
-        if (NW == 2) fout[(at + w) * NW + 1] = nhi[j];
+        const DKey<NW> nb = (j < 4) ? key_left<NW>(c, p, j) : key_right<NW>(c, p, j - 4);
+#pragma unroll
+        for (int q = 0; q < NW; q++) fout[(at + w) * NW + q] = nb.w[q];
         w++;
       }
     }
@@ -232,18 +293,12 @@ static __global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict
 
 // oriented neighbour of a (1,1) node: dir 0 = left, 1 = right, in the orientation `flipped` of its canonical key
 template <int NW>
-__device__ __forceinline__ void step11(const DbgParams& p, u64 clo, u64 chi, u32 info, bool flipped, int dir,
-                                       u64& olo, u64& ohi) {
+__device__ __forceinline__ DKey<NW> step11(const DbgParams& p, const DKey<NW>& c, u32 info, bool flipped, int dir) {
   // in canonical orientation the single left neighbour has base ffs(lmask), the right one ffs(rmask)
   const bool use_left = (dir == 0) != flipped;  // walking right in the flipped orientation = left in canonical
-  u64 nlo, nhi;
-  if (use_left) key_left<NW>(clo, chi, p.k, (u32)__ffs((int)(info & 15)) - 1, nlo, nhi);
-  else key_right<NW>(clo, chi, p, (u32)__ffs((int)((info >> 4) & 15)) - 1, nlo, nhi);
-  if (flipped) key_rc<NW>(nlo, nhi, p.k, olo, ohi);  // express the neighbour in the walker's orientation
-  else {
-    olo = nlo;
-    ohi = nhi;
-  }
+  const DKey<NW> n = use_left ? key_left<NW>(c, p, (u32)__ffs((int)(info & 15)) - 1)
+                              : key_right<NW>(c, p, (u32)__ffs((int)((info >> 4) & 15)) - 1);
+  return flipped ? key_rc<NW>(n, p) : n;  // express the neighbour in the walker's orientation
 }
 
 __device__ __forceinline__ bool is11(u32 info) { return __popc(info & 15) == 1 && __popc((info >> 4) & 15) == 1; }
@@ -259,12 +314,11 @@ static __global__ void __launch_bounds__(256) k_dbg_classify(DbgTab t, DbgParams
   u32 add = 0;
   if (!is11(info)) add = DBG_JUNCTION;
   else {
-    const u64 clo = t.klo[s], chi = (NW == 2) ? t.khi[s] : 0;
+    const DKey<NW> c = tab_key<NW>(t, s);
     for (int dir = 0; dir < 2; dir++) {
-      u64 nlo, nhi, ncl, nch;
-      step11<NW>(p, clo, chi, info, false, dir, nlo, nhi);
-      key_canon<NW>(nlo, nhi, p.k, ncl, nch);
-      const u64 ns = node_find<NW>(t, ncl, nch);
+      DKey<NW> nc;
+      key_canon<NW>(step11<NW>(p, c, info, false, dir), p, nc);
+      const u64 ns = node_find<NW>(t, nc);
       const u32 ninfo = (ns == DBG_NOSLOT) ? 0u : t.info[ns];
       // the run stops where the next node is not (1,1); a self-adjacent node also ends it (cycle guard)
       if (!is11(ninfo) || ns == s) add |= (dir == 0) ? DBG_ENDL : DBG_ENDR;
@@ -306,54 +360,44 @@ static __global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, 
     s = runs[tid].start_slot;
     flipped = runs[tid].start_flipped != 0;
   }
-  const u64 slo = t.klo[s], shi = (NW == 2) ? t.khi[s] : 0;
+  const DKey<NW> start = tab_key<NW>(t, s);
   u64 out = 0;
   if (PASS == 1) {
     out = seq_off[tid];
-    u64 olo, ohi;
-    if (flipped) key_rc<NW>(slo, shi, p.k, olo, ohi);
-    else {
-      olo = slo;
-      ohi = shi;
-    }
-    for (u32 i = 0; i < p.k; i++) {  // the start k-mer, first base first
-      const u32 bit = 2 * (p.k - 1 - i);
-      const u32 code = (u32)(((bit >= 64) ? (ohi >> (bit - 64)) : (olo >> bit)) & 3);
-      seq[out++] = "ACGT"[code];
-    }
+    const DKey<NW> o = flipped ? key_rc<NW>(start, p) : start;
+    for (u32 i = 0; i < p.k; i++) seq[out++] = "ACGT"[dkey_code<NW>(o, 2 * (p.k - 1 - i))];  // the start k-mer, first base first
     atomicOr(&t.info[s], DBG_INRUN | DBG_JOINT | (flipped ? DBG_JFLIP : 0u));
     t.nid[s] = (u32)tid;
   }
-  // current oriented node = canonical (clo,chi) walked in orientation cf; the start is never the last node of its
+  // current oriented node = canonical key `cur` walked in orientation cf; the start is never the last node of its
   // run (one-node runs became junctions in k_dbg_classify)
-  u64 clo = slo, chi = shi, cs = s;
+  DKey<NW> cur = start;
+  u64 cs = s;
   bool cf = flipped;
   u32 len = 1;
   for (u64 step = 0; step < max_steps; step++) {
     const u32 cinfo = t.info[cs];
-    u64 nlo, nhi, ncl, nch;
-    step11<NW>(p, clo, chi, cinfo, cf, 1, nlo, nhi);
-    const bool nf = key_canon<NW>(nlo, nhi, p.k, ncl, nch);
-    const u64 ns = node_find<NW>(t, ncl, nch);
+    const DKey<NW> nb = step11<NW>(p, cur, cinfo, cf, 1);
+    DKey<NW> nc;
+    const bool nf = key_canon<NW>(nb, p, nc);
+    const u64 ns = node_find<NW>(t, nc);
     if (ns == DBG_NOSLOT) break;  // cannot happen on a consistent table
-    clo = ncl;
-    chi = nch;
+    cur = nc;
     cs = ns;
     cf = nf;
     len++;
     const u32 ninfo = t.info[ns];
     const bool last = nf ? (ninfo & DBG_ENDL) != 0 : (ninfo & DBG_ENDR) != 0;  // end flag on the side we head to
     if (PASS == 1) {
-      seq[out++] = "ACGT"[(u32)(nlo & 3)];  // the last base of the oriented neighbour
+      seq[out++] = "ACGT"[(u32)(nb.w[0] & 3)];  // the last base of the oriented neighbour
       atomicOr(&t.info[ns], DBG_INRUN | (last ? (DBG_JOINT | DBG_JRIGHT) : 0u) | (nf ? DBG_JFLIP : 0u));
       t.nid[ns] = (u32)tid;
     }
     if (last) break;
   }
   if (PASS == 0) {
-    // the other end is (clo,chi): the end with the smaller canonical key registers the run
-    const bool mine = (NW == 1) ? (slo < clo) : (shi < chi || (shi == chi && slo < clo));
-    if (mine && len >= 2) {
+    // the other end is `cur`: the end with the smaller canonical key registers the run
+    if (dkey_less<NW>(start, cur) && len >= 2) {
       const u64 idx = atomicAdd((unsigned long long*)&ctr[4], 1ULL);
       runs[idx].start_slot = s;
       runs[idx].len = len;
@@ -369,58 +413,97 @@ static __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __rest
   if (s > t.cap_mask) return;
   if (!(t.info[s] & DBG_JUNCTION)) return;
   const u64 id = t.nid[s];
-  jkeys[id * NW] = t.klo[s];
-  if (NW == 2) jkeys[id * NW + 1] = t.khi[s];
+#pragma unroll
+  for (int j = 0; j < NW; j++) jkeys[id * NW + j] = t.kw[j][s];
 }
 
 // ---- k_dbg_coverage ------------------------------------------------------------------------------------------------
 // jcov[id*9 + 0] = coverage, [1..4] = left_kmers_cov, [5..8] = right_kmers_cov (junction stored in canonical orientation)
 // jtcov[2 * straight + 0 / 1] = JointInfo::coverage of the straight's left / right joint (:445-447: a window counts once
 // for the joint it equals in either orientation, twice when it is its own reverse complement)
+// One window of a read against the node table: `f` / `r` = its forward / reverse-complement key, pos = its start.
+template <int NW>
+__device__ __forceinline__ void dbg_cover_window(const DKey<NW>& f, const DKey<NW>& r, u64 pos, const u32* __restrict__ endm,
+                                                 const uint8_t* __restrict__ bases, u64 n_bases, const DbgTab& t,
+                                                 const DbgParams& p, u32* __restrict__ jcov, u32* __restrict__ jtcov) {
+  // junctions.find(kmer_Fw) / find(kmer_Bw): the stored key is the canonical one
+  const bool fcan = !dkey_less<NW>(r, f);  // f <= r
+  const bool both = dkey_eq<NW>(f, r);
+  DKey<NW> c;
+#pragma unroll
+  for (int j = 0; j < NW; j++) c.w[j] = fcan ? f.w[j] : r.w[j];
+  const u64 s = node_find<NW>(t, c);
+  if (s == DBG_NOSLOT) return;
+  const u32 info = t.info[s];
+  if (info & DBG_JOINT) atomicAdd(&jtcov[2 * (u64)t.nid[s] + ((info & DBG_JRIGHT) ? 1u : 0u)], both ? 2u : 1u);
+  if (info & DBG_JUNCTION) {
+    u32* cv = jcov + (u64)t.nid[s] * 9;
+    atomicAdd(&cv[0], both ? 2u : 1u);  // AddNodeCoverage(Fw) and (Bw) (:441-449)
+    const bool first = (pos == 0) || ((endm[(pos - 1) >> 5] >> ((pos - 1) & 31)) & 1);
+    const u64 endp = pos + p.k - 1;    // last base of the window
+    const bool has_next = !((endm[endp >> 5] >> (endp & 31)) & 1);
+    u32 nf = 0, nc = 0, pf = 0, pc = 0;
+    if (has_next && endp + 1 < n_bases) base_codes(bases[endp + 1], nf, nc);
+    if (!first) base_codes(bases[pos - 1], pf, pc);
+    if (first) {  // (:407-413) reads target_read[k] even when the read has exactly k bases ('\0' -> code 0)
+      if (fcan) atomicAdd(&cv[5 + nf], 1u);
+      else atomicAdd(&cv[1 + nc], 1u);
+    } else if (fcan) {  // (:424-429)
+      atomicAdd(&cv[1 + pf], 1u);
+      if (has_next) atomicAdd(&cv[5 + nf], 1u);
+    } else {  // (:430-435)
+      atomicAdd(&cv[5 + pc], 1u);
+      if (has_next) atomicAdd(&cv[1 + nc], 1u);
+    }
+  }
+}
+
 template <int NW>
 static __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restrict__ fw, const u64* __restrict__ rcw,
                                                       const u32* __restrict__ endm, const uint8_t* __restrict__ bases,
                                                       u64 n_bases, u64 n_words, DbgTab t, DbgParams p,
                                                       u32* __restrict__ jcov, u32* __restrict__ jtcov) {
   const u64 stride = (u64)gridDim.x * blockDim.x;
-  const u64 vmask = (1ULL << (p.k - 1)) - 1;
   for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
-    LaneWords L = load_lane_words(fw, rcw, endm, w);
-    KmerRoll<NW> kr;
-    kr.init(p.k, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
-    for (int j = 0; j < 32; j++) {
-      if ((L.Elo & vmask) == 0) {
-        const u64 pos = (w << 5) + j;  // window start; the window is [pos, pos+k)
-        // junctions.find(kmer_Fw) / find(kmer_Bw): the stored key is the canonical one
-        const bool fcan = (NW == 1) ? (kr.flo <= kr.rlo) : (kr.fhi < kr.rhi || (kr.fhi == kr.rhi && kr.flo <= kr.rlo));
-        const bool both = kr.flo == kr.rlo && kr.fhi == kr.rhi;
-        const u64 clo = fcan ? kr.flo : kr.rlo, chi = fcan ? kr.fhi : kr.rhi;
-        const u64 s = node_find<NW>(t, clo, chi);
-        if (s != DBG_NOSLOT && (t.info[s] & DBG_JOINT))
-          atomicAdd(&jtcov[2 * (u64)t.nid[s] + ((t.info[s] & DBG_JRIGHT) ? 1u : 0u)], both ? 2u : 1u);
-        if (s != DBG_NOSLOT && (t.info[s] & DBG_JUNCTION)) {
-          u32* c = jcov + (u64)t.nid[s] * 9;
-          atomicAdd(&c[0], both ? 2u : 1u);  // AddNodeCoverage(Fw) and (Bw) (:441-449)
-          const bool first = (pos == 0) || ((endm[(pos - 1) >> 5] >> ((pos - 1) & 31)) & 1);
-          const u64 endp = pos + p.k - 1;    // last base of the window
-          const bool has_next = !((endm[endp >> 5] >> (endp & 31)) & 1);
-          u32 nf = 0, nc = 0, pf = 0, pc = 0;
-          if (has_next && endp + 1 < n_bases) base_codes(bases[endp + 1], nf, nc);
-          if (!first) base_codes(bases[pos - 1], pf, pc);
-          if (first) {  // (:407-413) reads target_read[k] even when the read has exactly k bases ('\0' -> code 0)
-            if (fcan) atomicAdd(&c[5 + nf], 1u);
-            else atomicAdd(&c[1 + nc], 1u);
-          } else if (fcan) {  // (:424-429)
-            atomicAdd(&c[1 + pf], 1u);
-            if (has_next) atomicAdd(&c[5 + nf], 1u);
-          } else {  // (:430-435)
-            atomicAdd(&c[5 + pc], 1u);
-            if (has_next) atomicAdd(&c[1 + nc], 1u);
+    if constexpr (NW <= 2) {
+      const u64 vmask = (1ULL << (p.k - 1)) - 1;
+      LaneWords L = load_lane_words(fw, rcw, endm, w);
+      KmerRoll<NW> kr;
+      kr.init(p.k, L.W0, L.W1, L.W2, L.R0, L.R1, L.R2);
+      for (int j = 0; j < 32; j++) {
+        if ((L.Elo & vmask) == 0) {
+          DKey<NW> f, r;
+          f.w[0] = kr.flo;
+          r.w[0] = kr.rlo;
+          if constexpr (NW == 2) {
+            f.w[1] = kr.fhi;
+            r.w[1] = kr.rhi;
           }
+          dbg_cover_window<NW>(f, r, (w << 5) + j, endm, bases, n_bases, t, p, jcov, jtcov);
         }
+        kr.roll();
+        shr128(L.Elo, L.Ehi);
       }
-      kr.roll();
-      shr128(L.Elo, L.Ehi);
+    } else {
+      const u32 validk = ~wide_win32<false>(b192_load(endm, w), p.k - 1);  // no read end in [pos, pos + k - 1)
+      if (validk == 0) continue;
+      const u64 F[5] = {fw[w], fw[w + 1], fw[w + 2], fw[w + 3], fw[w + 4]};
+      const u64 R[5] = {rcw[w], rcw[w + 1], rcw[w + 2], rcw[w + 3], rcw[w + 4]};
+      WideRoll<NW> kr;
+      kr.init(p.k, F, R);
+      const u32 last = 31 - __clz((int)validk);
+      for (u32 j = 0; j <= last; j++) {
+        if ((validk >> j) & 1u) {
+          DKey<NW> f, r;
+#pragma unroll
+          for (int q = 0; q < NW; q++) {
+            f.w[q] = kr.f.w[q];
+            r.w[q] = kr.r.w[q];
+          }
+          dbg_cover_window<NW>(f, r, (w << 5) + j, endm, bases, n_bases, t, p, jcov, jtcov);
+        }
+        kr.roll();
+      }
     }
   }
 }
@@ -435,19 +518,17 @@ static __global__ void __launch_bounds__(256) k_dbg_edges(DbgTab t, DbgParams p,
   if (s > t.cap_mask) return;
   const u32 info = t.info[s];
   if (!(info & DBG_JUNCTION)) return;
-  const u64 clo = t.klo[s], chi = (NW == 2) ? t.khi[s] : 0;
+  const DKey<NW> c = tab_key<NW>(t, s);
   const u32 me = t.nid[s];
-  const u32* c = jcov + (u64)me * 9;
+  const u32* cv = jcov + (u64)me * 9;
   for (u32 side = 0; side < 2; side++) {
     for (u32 b = 0; b < 4; b++) {
-      if (c[1 + 4 * side + b] == 0) continue;
-      u64 nlo, nhi;
-      if (side == 0) key_left<NW>(clo, chi, p.k, b, nlo, nhi);
-      else key_right<NW>(clo, chi, p, b, nlo, nhi);
-      if (!bloom_has<NW>(bloom, p, nlo, nhi)) continue;
-      u64 ncl, nch;
-      const bool nf = key_canon<NW>(nlo, nhi, p.k, ncl, nch);
-      const u64 ns = node_find<NW>(t, ncl, nch);
+      if (cv[1 + 4 * side + b] == 0) continue;
+      const DKey<NW> n = (side == 0) ? key_left<NW>(c, p, b) : key_right<NW>(c, p, b);
+      if (!bloom_has<NW>(bloom, p, n)) continue;
+      DKey<NW> nc;
+      const bool nf = key_canon<NW>(n, p, nc);
+      const u64 ns = node_find<NW>(t, nc);
       if (ns == DBG_NOSLOT) continue;
       const u32 ninfo = t.info[ns];
       u32 other;

@@ -11,8 +11,8 @@
 // The stages hand their results on in HBM (AssembleResident); PLATANUS3_MATERIALISE=1 runs the reference-typed
 // Assemble<B> of the shim instead (same outputs; seconds of host time for the STL containers).
 //
-// What differs from the reference binary, on purpose: every k in [21,64] is dispatched (its switch has only 21, 25
-// and 63 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
+// What differs from the reference binary, on purpose: every k in [21,128] is dispatched (its switch has only 21, 25,
+// 63 and 101 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
 // graph closure explodes, no GPU -- ends with a message on stderr and exit status 3 rather than a silent "finish".
 #include <cstdlib>
 
@@ -36,7 +36,7 @@ struct Run {
     // maps) of Assemble<B>, as a caller written against them would; default: everything stays on the device
     const char* mat = std::getenv("PLATANUS3_MATERIALISE");
     const int status = (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
-    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..64)\n";
+    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..128)\n";
     log.WriteLog("finish");
     return status == 0 ? 0 : 3;
   }

@@ -12,8 +12,8 @@
 // the classes are re-declared with the reference's member names and filled from the flat results of the ABI.
 //
 // Differences a maintainer should know:
-//   * CountShortKmer / MakeBF take k in [21,128] (the reference's k = 101 included), the DeBruijnGraph stage k <= 64;
-//     unsupported k throws (the reference's Assemble_k silently returns 1, src/Assemble.cpp:51-52);
+//   * k in [21,128] (one to four key words; the reference's k = 101 included); unsupported k throws (the reference's
+//     Assemble_k silently returns 1, src/Assemble.cpp:51-52);
 //   * materialising the STL containers (17.7 M unordered_map inserts at config #2) costs seconds of host
 //     time -- callers that can consume flat arrays should use the C ABI directly;
 //   * BF<Key>::possiblyContains / add stay usable on the host object (the unchanged DeBruijnGraph code calls
@@ -597,9 +597,9 @@ int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
 // Same steps, same log lines, same output file as Assemble<B> above, but nothing is copied back to the host between
 // the stages: the count table, the Bloom vector, the seeds and the graph stay in HBM from p3_load_reads to
 // p3_write_gfa (the command line has no use for KmerCount / BF::m_bits / the three graph maps -- filling them is
-// 9 of the 10 s of a 1 M-read run).  k is checked by the library (21..64); other k return 1 like Assemble_k.
+// 9 of the 10 s of a 1 M-read run).  k is checked by the library (21..128); other k return 1 like Assemble_k.
 inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& logging) {
-  if (options.kmer_length < 21 || options.kmer_length > 64) return 1;
+  if (options.kmer_length < 21 || options.kmer_length > 128) return 1;
   logging.WriteLog("Assemble");
   p3shim::Session& s = p3shim::Session::get();
   s.load(input_reads.reads, options.kmer_length);
@@ -626,8 +626,9 @@ inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& lo
   return 0;
 }
 
-// Every k the device path supports (21..64) is dispatched -- the reference's switch (src/Assemble.cpp:31-53) only
-// has 21, 25 and 63 in that range; like there, any other k returns 1 without doing anything.
+// Every one- and two-word k (21..64) is dispatched, and the reference's own k = 101 (four words) -- the reference's
+// switch (src/Assemble.cpp:31-53) has 21, 25, 63 and 101 in the supported range; like there, any other k returns 1
+// without doing anything.  (AssembleResident takes every k in 21..128: it needs no std::bitset instance.)
 inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging) {
   switch (options.kmer_length) {
 #define P3SHIM_CASE(K) \
@@ -639,7 +640,7 @@ inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging)
     P3SHIM_CASE(42) P3SHIM_CASE(43) P3SHIM_CASE(44) P3SHIM_CASE(45) P3SHIM_CASE(46) P3SHIM_CASE(47) P3SHIM_CASE(48)
     P3SHIM_CASE(49) P3SHIM_CASE(50) P3SHIM_CASE(51) P3SHIM_CASE(52) P3SHIM_CASE(53) P3SHIM_CASE(54) P3SHIM_CASE(55)
     P3SHIM_CASE(56) P3SHIM_CASE(57) P3SHIM_CASE(58) P3SHIM_CASE(59) P3SHIM_CASE(60) P3SHIM_CASE(61) P3SHIM_CASE(62)
-    P3SHIM_CASE(63) P3SHIM_CASE(64)
+    P3SHIM_CASE(63) P3SHIM_CASE(64) P3SHIM_CASE(101)
 #undef P3SHIM_CASE
     default:
       return 1;

@@ -1,6 +1,6 @@
 """GPU tier: keys of three and four words (65 <= k <= 128; the reference's k = 101) through the C ABI -- count, gate,
 Bloom vector, seeds -- against golden vectors from the REAL reference (tests/golden/wide.json) and against the oracle on
-random reads.  The de Bruijn stage takes k <= 64 and must say so."""
+random reads; the de Bruijn stage against the reference's GFA (tests/golden/dbgw_*)."""
 import hashlib
 import json
 import os
@@ -114,17 +114,14 @@ def test_every_wide_k_on_one_read_set(oracle):
         ctx.close()
 
 
-def test_graph_stage_says_unsupported():
+def test_k_beyond_four_words_is_refused():
     b, o = synth.reads(seed=75, total_reads=300, read_len=200)
     ctx = capi.Context(0)
     try:
         ctx.load_reads(b, o, min_len=101)
-        ctx.run_pass(101, 1 << 22, 7)
         with pytest.raises(capi.P3Error) as e:
-            ctx.build_graph()
-        assert e.value.code == 2  # P3_EUNSUPPORTED_K
-        with pytest.raises(capi.P3Error):
             ctx.run_pass(129, 1 << 22, 7)
+        assert e.value.code == 2  # P3_EUNSUPPORTED_K
     finally:
         ctx.close()
 
@@ -162,3 +159,40 @@ def test_sharded_pass_with_wide_keys(oracle):
     for w, _ in res:
         assert np.array_equal(w, ewords)
     assert sorted(set(s for _, sd in res for s in sd)) == eseeds
+
+
+# ---- the de Bruijn stage for 3- and 4-word keys --------------------------------------------------------------------------
+def _dbgw_cases():
+    p = os.path.join(os.path.dirname(__file__), "golden", "dbgw_cases.json")
+    return json.load(open(p)) if os.path.exists(p) else []
+
+
+@pytest.mark.parametrize("case", _dbgw_cases(), ids=lambda c: c["name"])
+def test_wide_graph_matches_reference_gfa(tmp_path, case):
+    """MakeDBG + CountNodeCoverage + PrintGraph at k = 65 .. 128 against the REAL reference's GFA (-t 1) in ID-free
+    canonical form, and JointInfo::coverage against what the reference accumulated (tests/golden/make_golden_dbg_wide.py)"""
+    import gzip
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "dbgw_%s_reads.npz" % case["name"]))
+    k = case["k"]
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(z["bases"], z["offsets"], min_len=k)
+        ctx.run_pass(k, case["m"], case["H"])
+        st = ctx.build_graph()
+        assert st["n_junctions"] == case["n_junctions"] and st["n_straights"] == case["n_straights"]
+        path = os.path.join(str(tmp_path), "g.gfa")
+        ctx.write_gfa(path)
+        nodes, edges = canonical(open(path).read())
+        ls = canon_lines(nodes, edges)
+        with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "dbgw_%s.canon.gz" % case["name"]), "rt") as f:
+            assert ls == f.read().split("\n")
+        assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
+        joints = ctx.joint_coverage()
+        jl = ["%s\t%d" % (a, b) for a, b in joints]
+        g = case["joints"]
+        assert len(joints) == g["n"] and sum(b for _, b in joints) == g["coverage_sum"]
+        assert hashlib.sha256("\n".join(jl).encode()).hexdigest() == g["sha256"]
+    finally:
+        ctx.close()

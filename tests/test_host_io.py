@@ -12,6 +12,7 @@ import os
 import random
 import subprocess
 
+import numpy as np
 import pytest
 
 from platanus3_amd import _build
@@ -150,6 +151,38 @@ def test_command_line_end_to_end(tmp_path_factory, tmp_path, name, materialise):
         "start graph extention", "de bruijn graph loaded", "count node coverage", "finish"]
     if "n_seeds" in case:
         assert "seed kmer num= %d" % case["n_seeds"] in log
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("materialise", [0, 1])
+@pytest.mark.parametrize("name", ["synth1500_k101", "long40_k127"])
+def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
+    """platanus3 -k 101 -- a case of the reference's own switch (src/Assemble.cpp:40) -- and -k 127: four-word keys through
+    the command line, GFA against the real reference's (tests/golden/dbgw_*).  The reference-typed containers
+    (PLATANUS3_MATERIALISE=1: Assemble<std::bitset<202>>) exist for k = 101 only, as in the reference."""
+    import gzip
+    import hashlib
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    if materialise and name != "synth1500_k101":
+        pytest.skip("Assemble_k dispatches k = 101 of the wide keys")
+    case = [c for c in json.load(open(os.path.join(GOLDEN, "dbgw_cases.json"))) if c["name"] == name][0]
+    exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
+    z = np.load(os.path.join(GOLDEN, "dbgw_%s_reads.npz" % name))
+    b, off = z["bases"], z["offsets"]
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(off.size - 1):
+            f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
+    assert case["H"] == 10
+    subprocess.check_call([exe, "-i", fa, "-k", str(case["k"]), "-t", "1", "-m", str(case["m"])], cwd=str(tmp_path), timeout=180,
+                          env=dict(os.environ, PLATANUS3_MATERIALISE=str(materialise)))
+    nodes, edges = canonical(open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
+    ls = canon_lines(nodes, edges)
+    with gzip.open(os.path.join(GOLDEN, "dbgw_%s.canon.gz" % name), "rt") as f:
+        assert ls == f.read().split("\n")
+    assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
+    assert open(os.path.join(str(tmp_path), "platanus3.log")).read().rstrip().endswith("finish")
 
 
 @pytest.mark.gpu
