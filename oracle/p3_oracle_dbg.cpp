@@ -29,7 +29,81 @@ typedef unsigned __int128 u128;
 
 namespace {
 
-struct H128 {
+// Keys beyond two words (65 <= k <= 128): four 64-bit words, word 0 least significant, with the handful of operators the
+// restatement below uses.  The whole restatement is a template over the key type (u128 for k <= 64, U256 beyond).
+struct U256 {
+  uint64_t w[4];
+  U256() : w{0, 0, 0, 0} {}
+  U256(uint64_t v) : w{v, 0, 0, 0} {}  // NOLINT (implicit on purpose: small constants)
+  friend U256 operator<<(const U256& a, int n) {
+    U256 o;
+    const int ws = n >> 6, bs = n & 63;
+    for (int t = 3; t >= 0; t--) {
+      uint64_t v = 0;
+      if (t - ws >= 0) v = a.w[t - ws] << bs;
+      if (bs && t - ws - 1 >= 0) v |= a.w[t - ws - 1] >> (64 - bs);
+      o.w[t] = v;
+    }
+    return o;
+  }
+  friend U256 operator>>(const U256& a, int n) {
+    U256 o;
+    const int ws = n >> 6, bs = n & 63;
+    for (int t = 0; t < 4; t++) {
+      uint64_t v = 0;
+      if (t + ws < 4) v = a.w[t + ws] >> bs;
+      if (bs && t + ws + 1 < 4) v |= a.w[t + ws + 1] << (64 - bs);
+      o.w[t] = v;
+    }
+    return o;
+  }
+  friend U256 operator|(const U256& a, const U256& b) {
+    U256 o;
+    for (int t = 0; t < 4; t++) o.w[t] = a.w[t] | b.w[t];
+    return o;
+  }
+  friend U256 operator&(const U256& a, const U256& b) {
+    U256 o;
+    for (int t = 0; t < 4; t++) o.w[t] = a.w[t] & b.w[t];
+    return o;
+  }
+  friend bool operator==(const U256& a, const U256& b) { return std::memcmp(a.w, b.w, 32) == 0; }
+  friend bool operator<(const U256& a, const U256& b) {
+    for (int t = 3; t >= 0; t--)
+      if (a.w[t] != b.w[t]) return a.w[t] < b.w[t];
+    return false;
+  }
+  friend bool operator<=(const U256& a, const U256& b) { return !(b < a); }
+};
+
+inline uint64_t low64(const u128& v) { return (uint64_t)v; }
+inline uint64_t low64(const U256& v) { return v.w[0]; }
+inline void to_words(const u128& v, uint64_t* w) {
+  w[0] = (uint64_t)v;
+  w[1] = (uint64_t)(v >> 64);
+  w[2] = w[3] = 0;
+}
+inline void to_words(const U256& v, uint64_t* w) { std::memcpy(w, v.w, 32); }
+inline void from_words(const uint64_t* w, int nw, u128& v) {
+  v = w[0];
+  if (nw == 2) v |= (u128)w[1] << 64;
+}
+inline void from_words(const uint64_t* w, int nw, U256& v) {
+  v = U256();
+  for (int t = 0; t < nw; t++) v.w[t] = w[t];
+}
+template <typename K>
+inline K mask_of(int k);
+template <>
+inline u128 mask_of<u128>(int k) { return (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
+template <>
+inline U256 mask_of<U256>(int k) {
+  U256 m;
+  for (int b = 0; b < 2 * k; b++) m.w[b >> 6] |= 1ULL << (b & 63);
+  return m;
+}
+
+struct HKey {
   size_t operator()(const u128& v) const {
     uint64_t a = (uint64_t)v, b = (uint64_t)(v >> 64);
     a ^= b * 0x9E3779B97F4A7C15ULL;
@@ -38,52 +112,63 @@ struct H128 {
     a ^= a >> 32;
     return (size_t)a;
   }
+  size_t operator()(const U256& v) const {
+    uint64_t a = v.w[0];
+    for (int t = 1; t < 4; t++) {
+      a ^= v.w[t] * 0x9E3779B97F4A7C15ULL;
+      a ^= a >> 29;
+      a *= 0xBF58476D1CE4E5B9ULL;
+    }
+    a ^= a >> 32;
+    return (size_t)a;
+  }
 };
 
+template <typename K>
 struct Ctx {
   int k, H, nw;
   uint64_t m;
   const uint64_t* bloom;
-  u128 mask;
-  u128 rc(u128 x) const {
-    u128 o = 0;
+  K mask;
+  K rc(K x) const {
+    K o = 0;
     for (int i = 0; i < k; i++) {
-      o = (o << 2) | (u128)(3 - (unsigned)((x >> (2 * i)) & 3));
+      o = (o << 2) | K((uint64_t)(3 - (unsigned)(low64(x >> (2 * i)) & 3)));
     }
     return o;
   }
-  u128 canon(u128 x) const {
-    u128 r = rc(x);
+  K canon(K x) const {
+    K r = rc(x);
     return x <= r ? x : r;
   }
-  bool recorded(u128 x) const {  // IsRecorded, src/DeBruijnGraph.cpp:317-323
-    u128 c = canon(x);
-    uint64_t w[2] = {(uint64_t)c, (uint64_t)(c >> 64)};
+  bool recorded(K x) const {  // IsRecorded, src/DeBruijnGraph.cpp:317-323
+    K c = canon(x);
+    uint64_t w[4];
+    to_words(c, w);
     uint8_t out;
     p3o_bloom_query(bloom, m, H, w, 1, k, &out);
     return out != 0;
   }
-  u128 left_of(u128 x, unsigned b) const { return (x >> 2) | ((u128)b << (2 * k - 2)); }
-  u128 right_of(u128 x, unsigned b) const { return ((x << 2) | b) & mask; }
-  std::string str(u128 x) const {
+  K left_of(K x, unsigned b) const { return (x >> 2) | (K((uint64_t)b) << (2 * k - 2)); }
+  K right_of(K x, unsigned b) const { return ((x << 2) | K((uint64_t)b)) & mask; }
+  std::string str(K x) const {
     static const char b2c[4] = {'A', 'C', 'G', 'T'};
     std::string s((size_t)k, 'A');
-    for (int i = 0; i < k; i++) s[(size_t)i] = b2c[(unsigned)((x >> (2 * (k - 1 - i))) & 3)];
+    for (int i = 0; i < k; i++) s[(size_t)i] = b2c[(unsigned)(low64(x >> (2 * (k - 1 - i))) & 3)];
     return s;
   }
 };
 
+template <typename K>
 struct Node {
   uint8_t nl = 0, nr = 0;
-  u128 l[4], r[4];       // neighbours in the node's canonical orientation
+  K l[4], r[4];          // neighbours in the node's canonical orientation
   int junction_id = 0;   // > 0: junction
   int straight_id = 0;   // > 0: member of that straight
   bool joint = false;
   // junction counters (canonical orientation)
   int coverage = 0, lcov[4] = {0, 0, 0, 0}, rcov[4] = {0, 0, 0, 0};
 };
-
-typedef std::unordered_map<u128, Node, H128> NodeMap;
 
 inline unsigned fcode(char c) { return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0; }
 inline unsigned ccode(char c) { return c == 'A' ? 3 : c == 'C' ? 2 : c == 'G' ? 1 : 0; }  // comp. code; unknown -> 0
@@ -99,55 +184,57 @@ void p3o_free(char* p) { delete[] p; }
 // Returns the GFA text (reference format) in a new[]-allocated buffer (*out_text, *out_len); 0 on success.
 // joints_out (optional): "KMER\tcoverage\n" per joint, k-mer in its smaller orientation, sorted -- JointInfo::coverage
 // (src/DeBruijnGraph.cpp:24-28,441-449), which the reference fills but never prints.
-static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+template <typename K>
+static int dbg_impl_t(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
                     const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
                     char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights,
                     std::string* joints_out) {
-  if (k < 21 || k > 64) return 2;
-  Ctx cx;
+  typedef Node<K> Node;
+  typedef std::unordered_map<K, Node, HKey> NodeMap;
+  Ctx<K> cx;
   cx.k = k;
   cx.H = H;
   cx.m = m;
   cx.bloom = bloom_words;
   cx.nw = (2 * k + 63) / 64;
-  cx.mask = (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+  cx.mask = mask_of<K>(k);
   NodeMap nodes;
   // ---- closure of the seeds (G4) ----
-  std::deque<u128> q;
+  std::deque<K> q;
   for (uint64_t i = 0; i < n_seeds; i++) {
-    u128 s = seed_keys[i * cx.nw];
-    if (cx.nw == 2) s |= (u128)seed_keys[i * cx.nw + 1] << 64;
+    K s;
+    from_words(seed_keys + i * cx.nw, cx.nw, s);
     q.push_back(s);
   }
   while (!q.empty()) {
-    u128 c = cx.canon(q.front());
+    K c = cx.canon(q.front());
     q.pop_front();
     if (nodes.count(c)) continue;
     Node n;
     for (unsigned b = 0; b < 4; b++) {
-      u128 a = cx.left_of(c, b);
+      K a = cx.left_of(c, b);
       if (cx.recorded(a)) n.l[n.nl++] = a;
     }
     for (unsigned b = 0; b < 4; b++) {
-      u128 a = cx.right_of(c, b);
+      K a = cx.right_of(c, b);
       if (cx.recorded(a)) n.r[n.nr++] = a;
     }
     nodes.emplace(c, n);
     for (int i = 0; i < n.nl; i++) q.push_back(n.l[i]);
     for (int i = 0; i < n.nr; i++) q.push_back(n.r[i]);
   }
-  auto is11 = [&](u128 oriented) {
+  auto is11 = [&](K oriented) {
     const Node& n = nodes.at(cx.canon(oriented));
     return n.nl == 1 && n.nr == 1;
   };
   // oriented right / left neighbour of an oriented (1,1) node
-  auto right1 = [&](u128 x) {
-    u128 c = cx.canon(x);
+  auto right1 = [&](K x) {
+    K c = cx.canon(x);
     const Node& n = nodes.at(c);
     return x == c ? n.r[0] : cx.rc(n.l[0]);
   };
-  auto left1 = [&](u128 x) {
-    u128 c = cx.canon(x);
+  auto left1 = [&](K x) {
+    K c = cx.canon(x);
     const Node& n = nodes.at(c);
     return x == c ? n.l[0] : cx.rc(n.r[0]);
   };
@@ -155,36 +242,36 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
   int junction_id = 0, straight_id = 0;
   struct Straight {
     std::string seq;
-    u128 left_joint, right_joint;  // oriented as in seq
+    K left_joint, right_joint;  // oriented as in seq
   };
   std::vector<Straight> straights;
-  std::unordered_map<u128, int, H128> joint_of;  // oriented joint k-mer (as stored) -> straight id
-  std::vector<u128> order;
+  std::unordered_map<K, int, HKey> joint_of;  // oriented joint k-mer (as stored) -> straight id
+  std::vector<K> order;
   order.reserve(nodes.size());
   for (auto& kv : nodes) order.push_back(kv.first);
   std::sort(order.begin(), order.end());  // deterministic ids
-  for (u128 c : order) {
+  for (K c : order) {
     Node& n = nodes[c];
     if (!(n.nl == 1 && n.nr == 1)) n.junction_id = ++junction_id;
   }
   const size_t guard = nodes.size() + 2;
-  for (u128 c : order) {
+  for (K c : order) {
     Node& n = nodes[c];
     if (n.junction_id || n.straight_id) continue;
     // walk left to the start of the run (orientation: canonical orientation of c)
-    u128 start = c;
+    K start = c;
     size_t steps = 0;
     while (steps++ < guard) {
-      u128 p = left1(start);
+      K p = left1(start);
       if (!is11(p) || cx.canon(p) == cx.canon(c)) break;
       start = p;
     }
     // walk right collecting the run
-    std::vector<u128> run;
+    std::vector<K> run;
     run.push_back(start);
     steps = 0;
     while (steps++ < guard) {
-      u128 nx = right1(run.back());
+      K nx = right1(run.back());
       if (!is11(nx) || cx.canon(nx) == cx.canon(start)) break;
       run.push_back(nx);
     }
@@ -195,19 +282,19 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
     Straight st;
     st.seq = cx.str(run[0]);
     static const char b2c[4] = {'A', 'C', 'G', 'T'};
-    for (size_t i = 1; i < run.size(); i++) st.seq += b2c[(unsigned)(run[i] & 3)];
+    for (size_t i = 1; i < run.size(); i++) st.seq += b2c[(unsigned)(low64(run[i]) & 3)];
     st.left_joint = run.front();
     st.right_joint = run.back();
     straights.push_back(st);
     ++straight_id;
-    for (u128 x : run) nodes[cx.canon(x)].straight_id = straight_id;
+    for (K x : run) nodes[cx.canon(x)].straight_id = straight_id;
     nodes[cx.canon(run.front())].joint = true;
     nodes[cx.canon(run.back())].joint = true;
     joint_of[run.front()] = straight_id;
     joint_of[run.back()] = straight_id;
   }
   // ---- coverage (G5): junction keys are stored in canonical orientation here ----
-  auto junction_at = [&](u128 key) -> Node* {  // exact-orientation lookup, like junctions.find(key)
+  auto junction_at = [&](K key) -> Node* {  // exact-orientation lookup, like junctions.find(key)
     auto it = nodes.find(key);
     if (it == nodes.end() || !it->second.junction_id) return nullptr;
     return &it->second;  // map key == canonical == stored orientation
@@ -216,10 +303,10 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
     const char* s = bases + offsets[r];
     const uint64_t L = offsets[r + 1] - offsets[r];
     if (L < min_len || L < (uint64_t)k) continue;
-    u128 fw = 0, bw = 0;
+    K fw = 0, bw = 0;
     for (uint64_t i = 0; i < L; i++) {
-      fw = ((fw << 2) | fcode(s[i])) & cx.mask;
-      bw = (bw >> 2) | ((u128)ccode(s[i]) << (2 * k - 2));
+      fw = ((fw << 2) | K((uint64_t)fcode(s[i]))) & cx.mask;
+      bw = (bw >> 2) | (K((uint64_t)ccode(s[i])) << (2 * k - 2));
       if (i + 1 < (uint64_t)k) continue;
       Node* jf = junction_at(fw);
       Node* jb = junction_at(bw);
@@ -250,13 +337,13 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
   std::string out = "H\tVN:Z:1.0\n";
   for (size_t i = 0; i < straights.size(); i++)
     out += "S\tStraight_" + std::to_string(i + 1) + "\t" + straights[i].seq + "\tKC:i:" + std::to_string(straights[i].seq.size()) + "\n";
-  for (u128 c : order) {
+  for (K c : order) {
     const Node& n = nodes[c];
     if (n.junction_id)
       out += "S\tJunction_" + std::to_string(n.junction_id) + "\t" + cx.str(c) + "\tKC:i:" + std::to_string((long long)n.coverage * k) + "\n";
   }
   const std::string ov = std::to_string(k - 1) + "M\n";
-  auto name_of = [&](u128 x, std::string& nm, char& orient) -> bool {
+  auto name_of = [&](K x, std::string& nm, char& orient) -> bool {
     // junctions.find(x) / joints.find(x), then the complement (:474-505)
     if (Node* j = junction_at(x)) {
       nm = "Junction_" + std::to_string(j->junction_id);
@@ -269,7 +356,7 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
       orient = '+';
       return true;
     }
-    u128 y = cx.rc(x);
+    K y = cx.rc(x);
     if (Node* j = junction_at(y)) {
       nm = "Junction_" + std::to_string(j->junction_id);
       orient = '-';
@@ -283,13 +370,13 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
     }
     return false;
   };
-  for (u128 c : order) {
+  for (K c : order) {
     const Node& n = nodes[c];
     if (!n.junction_id) continue;
     const std::string me = "Junction_" + std::to_string(n.junction_id);
     for (unsigned b = 0; b < 4; b++) {
       if (n.lcov[b] == 0) continue;
-      u128 a = cx.left_of(c, b);
+      K a = cx.left_of(c, b);
       if (!cx.recorded(a)) continue;
       std::string nm;
       char o;
@@ -297,7 +384,7 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
     }
     for (unsigned b = 0; b < 4; b++) {
       if (n.rcov[b] == 0) continue;
-      u128 a = cx.right_of(c, b);
+      K a = cx.right_of(c, b);
       if (!cx.recorded(a)) continue;
       std::string nm;
       char o;
@@ -319,6 +406,18 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
     for (auto& j : jl) *joints_out += j.first + "\t" + std::to_string(j.second) + "\n";
   }
   return 0;
+}
+
+static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k,
+                    const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
+                    char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights,
+                    std::string* joints_out) {
+  if (k < 21 || k > 128) return 2;
+  if (k <= 64)
+    return dbg_impl_t<u128>(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len,
+                            n_junctions, n_joints, n_straights, joints_out);
+  return dbg_impl_t<U256>(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len,
+                          n_junctions, n_joints, n_straights, joints_out);
 }
 
 extern "C" {

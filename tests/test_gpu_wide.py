@@ -196,3 +196,28 @@ def test_wide_graph_matches_reference_gfa(tmp_path, case):
         assert hashlib.sha256("\n".join(jl).encode()).hexdigest() == g["sha256"]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("k,n,L,m,H", [(65, 3000, 250, 1 << 21, 4), (101, 4000, 250, None, None), (128, 3000, 300, 1 << 20, 3),
+                                       (77, 60, 3000, 1 << 21, 5)])
+def test_wide_graph_vs_oracle(oracle, tmp_path, k, n, L, m, H):
+    """inputs beyond the goldens: the device graph against the oracle's restatement (itself pinned on the ten goldens)"""
+    from gfa_canon import canonical
+    b, off = synth.reads(seed=90 + k, total_reads=n, read_len=L, sub_rate_ppm=6000)
+    if m is None:
+        m, H = 1 << 22, 10
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(b, off, min_len=k)
+        ctx.run_pass(k, m, H)
+        st = ctx.build_graph()
+        path = os.path.join(str(tmp_path), "g.gfa")
+        ctx.write_gfa(path)
+        keys, counts = oracle.count_short((b, off), min_len=k)
+        words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+        want, ost = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
+        assert st["n_junctions"] == ost["junctions"] and st["n_straights"] == ost["straights"]
+        assert canonical(open(path).read()) == canonical(want)
+        assert ctx.joint_coverage() == oracle.dbg_joints((b, off), words, m, H, seeds, k)
+    finally:
+        ctx.close()
