@@ -192,6 +192,20 @@ typedef struct {
   float ms_total;  /* first event to last event of the most recent pass    */
 } p3_timings;
 int p3_last_timings(p3_ctx* ctx, p3_timings* out);
+/* Byte counters of the most recent pass, per phase: the ALGORITHMIC bytes of SURVEY.md section 8d -- what a perfect
+ * implementation has to move between HBM and the chip (every base read once per stage, every window's 8-byte record
+ * written and read once, 16 bytes per distinct (key, count), the Bloom vector written once).  bytes / ms of
+ * p3_last_timings = achieved algorithmic bandwidth of the phase; bench.py's `roofline` uses the same accounting.
+ * (Counter traffic -- what the kernels actually move -- is measured with rocprofv3 --pmc, profiles/.) */
+typedef struct {
+  uint64_t bytes_pack;   /* bases read                                              */
+  uint64_t bytes_count;  /* 16 B per valid 21-window + 16 B per distinct 21-mer     */
+  uint64_t bytes_gate;   /* 0: the gate is a by-product of the count stage          */
+  uint64_t bytes_bloom;  /* bases read again + m/8 bytes of vector                  */
+  uint64_t bytes_seeds;  /* 0                                                       */
+  uint64_t bytes_total;
+} p3_traffic;
+int p3_last_traffic(p3_ctx* ctx, p3_traffic* out);
 /* per-kernel stats accumulated while profiling is on: name (<= 63 chars), launches, total ms.
  * idx in [0, p3_kernel_stat_count).  p3_reset_kernel_stats clears them. */
 int p3_kernel_stat_count(p3_ctx* ctx);

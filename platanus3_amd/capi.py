@@ -40,6 +40,10 @@ class Timings(C.Structure):
                 ("ms_seeds", C.c_float), ("ms_total", C.c_float)]
 
 
+class Traffic(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("bytes_pack", "bytes_count", "bytes_gate", "bytes_bloom", "bytes_seeds", "bytes_total")]
+
+
 P3_MAX_RANKS = 64
 
 
@@ -123,6 +127,7 @@ def load(build=False):
     L.p3_mr_or_reduce.argtypes = [vp, vp, vp, u64, u32, u64]
     L.p3_mr_alloc_scratch.argtypes = [vp, u64, C.POINTER(vp)]
     L.p3_last_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.p3_last_traffic.argtypes = [vp, C.POINTER(Traffic)]
     L.p3_kernel_stat_count.argtypes = [vp]
     L.p3_kernel_stat.argtypes = [vp, C.c_int, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
     L.p3_reset_kernel_stats.argtypes = [vp]
@@ -376,6 +381,12 @@ class Context:
         t = Timings()
         self._chk(self.L.p3_last_timings(self.h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in Timings._fields_}
+
+    def traffic(self):
+        """algorithmic bytes of the last pass per phase (SURVEY.md section 8d accounting)"""
+        t = Traffic()
+        self._chk(self.L.p3_last_traffic(self.h, C.byref(t)))
+        return {f: int(getattr(t, f)) for f, _ in Traffic._fields_}
 
     def kernel_stats(self):
         out = {}

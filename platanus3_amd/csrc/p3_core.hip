@@ -409,6 +409,20 @@ int p3_last_timings(p3_ctx* c, p3_timings* out) {
   return P3_OK;
 }
 
+int p3_last_traffic(p3_ctx* c, p3_traffic* out) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->counted) return fail(c, P3_ESTATE, "no pass yet");
+  p3_traffic t{};
+  t.bytes_pack = c->n_bases;
+  t.bytes_count = 16 * c->cstats.n_windows + 16 * c->cstats.n_distinct;
+  t.bytes_gate = 0;
+  t.bytes_bloom = c->bloomed ? c->n_bases + (c->m + 7) / 8 : 0;
+  t.bytes_seeds = 0;
+  t.bytes_total = t.bytes_pack + t.bytes_count + t.bytes_bloom;
+  *out = t;
+  return P3_OK;
+}
+
 int p3_kernel_stat_count(p3_ctx* c) {
   if (!c) return 0;
   if (drain_stats(c) != P3_OK) return 0;

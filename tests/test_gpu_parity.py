@@ -110,6 +110,22 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
     assert ctx.count_short()["n_distinct"] == 0
 
 
+def test_timings_and_byte_counters(ctx):
+    """p3_last_timings / p3_last_traffic (per-phase device times and byte counters): the counters
+    follow section 8d's accounting -- 2 L + 16 (L - 20) + 16 D / R + m / (8 R) bytes per read in total"""
+    n, L, k = 5000, 150, 31
+    b, o = synth.reads(seed=9, total_reads=n, read_len=L)
+    m, H = 4000037, 7
+    ctx.load_reads(b, o, min_len=k)
+    ctx.run_pass(k, m, H)
+    t, tr, cs = ctx.timings(), ctx.traffic(), ctx.count_stats()
+    assert t["ms_total"] > 0 and t["ms_count"] > 0 and t["ms_bloom"] > 0
+    assert tr["bytes_pack"] == n * L and tr["bytes_gate"] == 0 and tr["bytes_seeds"] == 0
+    assert tr["bytes_count"] == 16 * n * (L - 20) + 16 * cs["n_distinct"]
+    assert tr["bytes_bloom"] == n * L + (m + 7) // 8
+    assert tr["bytes_total"] == tr["bytes_pack"] + tr["bytes_count"] + tr["bytes_bloom"]
+
+
 def test_error_codes(ctx):
     b, o = synth.reads(seed=1, total_reads=50, read_len=100)
     ctx.load_reads(b, o, min_len=31)
