@@ -310,6 +310,11 @@ int p3_comm_create_member(p3_comm** out, p3_group* group, uint32_t local_index);
  * vector, OR-merge: all-to-all of word chunks + all-gather).  Calls p3_mr_config(ctx, rank, n_ranks of comm) itself.
  * Afterwards the count table is sharded by bucket owner and every rank holds the whole Bloom vector. */
 int p3_mr_run_pass(p3_ctx* ctx, p3_comm* comm, uint32_t k, uint64_t m_bits, uint32_t H);
+/* The de Bruijn stage of a sharded job, after p3_mr_run_pass (every rank calls it): rank 0 gathers the ranks' seeds and
+ * builds the structure (MakeDBG), the node table goes to every rank, every rank counts the coverage of ITS reads against
+ * it (CountNodeCoverage), the counters are summed, rank 0 emits the links.  Afterwards rank 0 holds the graph
+ * (p3_get_graph_stats, p3_export_*, p3_write_gfa); it equals the single-rank graph of the union of the reads. */
+int p3_mr_build_graph(p3_ctx* ctx, p3_comm* comm);
 
 /* ---- synthetic workload (plain C, CPU) -------------------------------------- */
 uint64_t p3_synth_genome_length(uint64_t total_reads, uint32_t read_len, uint32_t coverage);

@@ -374,4 +374,14 @@ struct ChunkView {
   ~ChunkView() { restore(); }
 };
 
+// ---- p3_exchange.hip: the communicator's collectives for the other units ----------------------------------------------
+int xc_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
+            u32 elem, hipStream_t st);
+int xc_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hipStream_t st);
+int xc_allreduce(p3_comm* cm, u64* v, u32 n, int op, hipStream_t st);  // op 0 = max, 1 = sum; n <= 64 host values
+u32 xc_rank(const p3_comm* cm);
+u32 xc_size(const p3_comm* cm);
+const char* xc_error(const p3_comm* cm);
+void xc_abort(p3_comm* cm);  // a group member that fails releases the others
+
 }  // namespace p3i

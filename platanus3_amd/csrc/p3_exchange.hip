@@ -389,6 +389,24 @@ int exchange_counts(p3_ctx* c, p3_comm* cm, const u64* send, u64* recv) {
 
 }  // namespace
 
+// the collectives for the other units (p3_graph.hip: the sharded de Bruijn stage)
+namespace p3i {
+int xc_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
+            u32 elem, hipStream_t st) {
+  return comm_a2av(cm, d_send, soff, scnt, d_recv, roff, rcnt, elem, st);
+}
+int xc_allgather(p3_comm* cm, const void* d_send, void* d_recv, u64 bytes, hipStream_t st) {
+  return comm_allgather(cm, d_send, d_recv, bytes, st);
+}
+int xc_allreduce(p3_comm* cm, u64* v, u32 n, int op, hipStream_t st) { return comm_allreduce(cm, v, n, op, st); }
+u32 xc_rank(const p3_comm* cm) { return cm->rank; }
+u32 xc_size(const p3_comm* cm) { return cm->n_ranks; }
+const char* xc_error(const p3_comm* cm) { return cm->err.c_str(); }
+void xc_abort(p3_comm* cm) {
+  if (cm->group) cm->group->abort();
+}
+}  // namespace p3i
+
 extern "C" {
 
 const char* p3_comm_last_error(const p3_comm* cm) { return cm ? cm->err.c_str() : "null communicator"; }

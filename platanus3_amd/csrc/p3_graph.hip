@@ -6,23 +6,48 @@ using namespace p3i;
 namespace {
 
 // ---- de Bruijn stage (G3-G6) -------------------------------------------------------------------------------------
+// Three phases, so that a sharded job can run the middle one on every rank's reads:
+//   A  graph_structure   closure of the seeds, classification, runs and their sequences (MakeDBG, :93-391)
+//   B  graph_coverage    CountNodeCoverage (:393-449) of THIS context's reads into the junction / joint counters
+//   C  graph_links       the L lines (:468-543) and the junction keys by id; statistics
 template <int NW>
-int build_graph_t(p3_ctx* c) {
-  int rc;
-  const u32 k = c->k;
+DbgParams graph_params(const p3_ctx* c) {
   DbgParams p;
-  p.k = k;
+  p.k = c->k;
   p.H = c->H;
   p.mm = make_modm(c->m);
-  p.top_bits = 2 * k - 64 * (NW - 1);  // 2 .. 64
+  p.top_bits = 2 * c->k - 64 * (NW - 1);  // 2 .. 64
   p.mask_top = p.top_bits == 64 ? ~0ULL : ((1ULL << p.top_bits) - 1);
+  return p;
+}
+
+DbgTab graph_table(const p3_ctx* c) {
+  return DbgTab{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p,
+                c->g_cap - 1};
+}
+
+// table buffers for `cap` slots (the frontier buffers only where the closure runs)
+template <int NW>
+int graph_alloc_table(p3_ctx* c, u64 cap) {
+  int rc;
   DevBuf* kbuf[4] = {&c->g_klo, &c->g_khi, &c->g_k2, &c->g_k3};
+  for (int j = 0; j < NW; j++)
+    if ((rc = ensure(c, *kbuf[j], cap * 8))) return rc;
+  if ((rc = ensure(c, c->g_info, cap * 4))) return rc;
+  if ((rc = ensure(c, c->g_nid, cap * 4))) return rc;
+  c->g_cap = cap;
+  return P3_OK;
+}
+
+// A.  seeds: n_in keys of NW words (+ optional validity bytes); est = expected number of nodes (sizes the table)
+template <int NW>
+int graph_structure(p3_ctx* c, const u64* seed_keys, const uint8_t* seed_valid, u64 n_seeds_in, u64 est) {
+  int rc;
+  const u32 k = c->k;
+  const DbgParams p = graph_params<NW>(c);
   if ((rc = ensure(c, c->g_ctr, 16 * 8))) return rc;
   u64* ctr = (u64*)c->g_ctr.p;
   // table capacity: a few times the number of distinct inserted k-mers (false-positive neighbours add nodes)
-  u64 est = c->n_distinct_k ? c->n_distinct_k : c->bstats.n_passing;
-  if (est > c->n_bases) est = c->n_bases;
-  if (est < c->bstats.n_seed_reads) est = c->bstats.n_seed_reads;
   u64 cap = 1 << 12;
   while (cap < 3 * est + 4096) cap <<= 1;
   u64 hc[16];
@@ -34,24 +59,20 @@ int build_graph_t(p3_ctx* c) {
     if (attempt > 3)
       return fail(c, P3_ECAPACITY, "de Bruijn closure exceeds %llu nodes: Bloom filter too dense for a finite graph",
                   (unsigned long long)(cap / 8));
-    c->g_cap = cap;
     const u64 node_limit = cap / 2 + cap / 8;  // 62 % load at most
     const u64 fcap = 8 * node_limit + 64;       // every inserted node appends at most 8 neighbours
-    for (int j = 0; j < NW; j++)
-      if ((rc = ensure(c, *kbuf[j], cap * 8))) return rc;
-    if ((rc = ensure(c, c->g_info, cap * 4))) return rc;
-    if ((rc = ensure(c, c->g_nid, cap * 4))) return rc;
+    if ((rc = graph_alloc_table<NW>(c, cap))) return rc;
     if ((rc = ensure(c, c->g_f0, fcap * 8 * NW))) return rc;
     if ((rc = ensure(c, c->g_f1, fcap * 8 * NW))) return rc;
     HIPCHK(c, hipMemsetAsync(c->g_klo.p, 0xff, cap * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->g_info.p, 0, cap * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->g_nid.p, 0, cap * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(ctr, 0, 16 * 8, c->stream));
-    DbgTab t{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
-    // level 0: the per-read seed keys (MakeDBG iterates the seed set, :96-105)
-    const u64* fin = (const u64*)c->seeds.p;
-    const uint8_t* fvalid = (const uint8_t*)c->seed_valid.p;
-    u64 n_in = c->n_reads;
+    const DbgTab t = graph_table(c);
+    // level 0: the seed keys (MakeDBG iterates the seed set, :96-105)
+    const u64* fin = seed_keys;
+    const uint8_t* fvalid = seed_valid;
+    u64 n_in = n_seeds_in;
     DevBuf* outb = &c->g_f0;
     bool overflow = false;
     levels = 0;
@@ -75,7 +96,7 @@ int build_graph_t(p3_ctx* c) {
     cap <<= 2;
   }
   const u64 n_nodes = hc[1];
-  DbgTab t{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p, cap - 1};
+  const DbgTab t = graph_table(c);
   LAUNCH(c, "k_dbg_classify", (k_dbg_classify<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, ctr);
   // runs: pass 0 registers them, the host lays the sequences out, pass 1 writes them
   if ((rc = ensure(c, c->g_runs, (n_nodes / 2 + 16) * sizeof(DbgRun)))) return rc;
@@ -95,35 +116,173 @@ int build_graph_t(p3_ctx* c) {
   if (n_runs)
     LAUNCH(c, "k_dbg_walk1", (k_dbg_walk<NW, 1>), grid_for(n_runs, 256, 1u << 30), 256, t, p, (DbgRun*)c->g_runs.p,
            (const u64*)c->g_seqoff.p, (char*)c->g_seq.p, n_runs, ctr, n_nodes + 2);
-  // coverage (G5) and edges (G6)
-  if ((rc = ensure(c, c->g_jcov, (n_junc + 1) * 9 * 4))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->g_jcov.p, 0, (n_junc + 1) * 9 * 4, c->stream));
-  if ((rc = ensure(c, c->g_jtcov, (2 * n_runs + 2) * 4))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->g_jtcov.p, 0, (2 * n_runs + 2) * 4, c->stream));
-  LAUNCH(c, "k_dbg_coverage", (k_dbg_coverage<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-         (const u32*)c->endm.p, c->d_bases, c->n_bases, c->n_words, t, p, (u32*)c->g_jcov.p, (u32*)c->g_jtcov.p);
-  const u64 edge_cap = 8 * n_junc + 8;
-  if ((rc = ensure(c, c->g_edges, edge_cap * 8))) return rc;
-  LAUNCH(c, "k_dbg_edges", (k_dbg_edges<NW>), grid_for(cap, 256, 1u << 30), 256, t, p, (const u32*)c->bloom.p,
-         (const u32*)c->g_jcov.p, (uint2*)c->g_edges.p, edge_cap, ctr);
-  if ((rc = ensure(c, c->g_jkeys, (n_junc + 1) * 8 * NW))) return rc;
-  LAUNCH(c, "k_dbg_gather", (k_dbg_gather<NW>), grid_for(cap, 256, 1u << 30), 256, t, (u64*)c->g_jkeys.p);
-  HIPCHK(c, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gstats_ = p3_graph_stats{};
   c->gstats_.n_nodes = n_nodes;
   c->gstats_.n_junctions = n_junc;
   c->gstats_.n_straights = n_runs;
   c->gstats_.n_joints = 2 * n_runs;
   c->gstats_.straight_bases = seq_total;
-  c->gstats_.n_edges = hc[5];
   c->gstats_.levels = levels;
+  return P3_OK;
+}
+
+// B.  (the table and the counts of junctions / straights are in place: built here or received from the rank that built them)
+template <int NW>
+int graph_coverage(p3_ctx* c) {
+  int rc;
+  const u64 n_junc = c->gstats_.n_junctions, n_runs = c->gstats_.n_straights;
+  if ((rc = ensure(c, c->g_jcov, (n_junc + 1) * 9 * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->g_jcov.p, 0, (n_junc + 1) * 9 * 4, c->stream));
+  if ((rc = ensure(c, c->g_jtcov, (2 * n_runs + 2) * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->g_jtcov.p, 0, (2 * n_runs + 2) * 4, c->stream));
+  LAUNCH(c, "k_dbg_coverage", (k_dbg_coverage<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+         (const u32*)c->endm.p, c->d_bases, c->n_bases, c->n_words, graph_table(c), graph_params<NW>(c), (u32*)c->g_jcov.p,
+         (u32*)c->g_jtcov.p);
+  return P3_OK;
+}
+
+// C.
+template <int NW>
+int graph_links(p3_ctx* c) {
+  int rc;
+  const u64 n_junc = c->gstats_.n_junctions, cap = c->g_cap;
+  u64* ctr = (u64*)c->g_ctr.p;
+  const DbgTab t = graph_table(c);
+  const u64 edge_cap = 8 * n_junc + 8;
+  if ((rc = ensure(c, c->g_edges, edge_cap * 8))) return rc;
+  LAUNCH(c, "k_dbg_edges", (k_dbg_edges<NW>), grid_for(cap, 256, 1u << 30), 256, t, graph_params<NW>(c), (const u32*)c->bloom.p,
+         (const u32*)c->g_jcov.p, (uint2*)c->g_edges.p, edge_cap, ctr);
+  if ((rc = ensure(c, c->g_jkeys, (n_junc + 1) * 8 * NW))) return rc;
+  LAUNCH(c, "k_dbg_gather", (k_dbg_gather<NW>), grid_for(cap, 256, 1u << 30), 256, t, (u64*)c->g_jkeys.p);
+  u64 hc[8];
+  HIPCHK(c, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->gstats_.n_edges = hc[5];
   c->graphed = true;
   return P3_OK;
+}
+
+u64 graph_node_estimate(const p3_ctx* c) {
+  u64 est = c->n_distinct_k ? c->n_distinct_k : c->bstats.n_passing;
+  if (est > c->n_bases) est = c->n_bases;
+  if (est < c->bstats.n_seed_reads) est = c->bstats.n_seed_reads;
+  return est;
+}
+
+template <int NW>
+int build_graph_t(p3_ctx* c) {
+  int rc;
+  c->graphed = false;
+  if ((rc = graph_structure<NW>(c, (const u64*)c->seeds.p, (const uint8_t*)c->seed_valid.p, c->n_reads, graph_node_estimate(c)))) return rc;
+  if ((rc = graph_coverage<NW>(c))) return rc;
+  return graph_links<NW>(c);
+}
+
+// The de Bruijn stage of a sharded job (after p3_mr_run_pass: every rank holds the whole Bloom vector, its own reads and
+// their seeds).  Rank 0 gathers the seeds and builds the structure; the node table goes to every rank; every rank counts
+// the coverage of ITS reads against it; the counters are summed; rank 0 emits the links.  Only rank 0 ends up with the
+// graph (p3_write_gfa / the exports).
+template <int NW>
+int mr_build_graph_t(p3_ctx* c, p3_comm* cm) {
+  int rc;
+  const u32 W = xc_size(cm), r = xc_rank(cm);
+  if (W > P3_MAX_RANKS) return fail(c, P3_EBADARG, "too many ranks");
+#define XC(expr)                                                    \
+  do {                                                              \
+    if ((rc = (expr))) return fail(c, rc, "%s", xc_error(cm));      \
+  } while (0)
+  c->graphed = false;
+  // ---- seeds of every rank -> rank 0
+  u64 nreads[P3_MAX_RANKS] = {0};
+  nreads[r] = c->n_reads;
+  XC(xc_allreduce(cm, nreads, W, 1, c->stream));
+  u64 est = graph_node_estimate(c);
+  XC(xc_allreduce(cm, &est, 1, 1, c->stream));
+  u64 soff[P3_MAX_RANKS] = {0}, scnt[P3_MAX_RANKS] = {0}, roff[P3_MAX_RANKS] = {0}, rcnt[P3_MAX_RANKS] = {0};
+  u64 total = 0;
+  scnt[0] = c->n_reads;
+  if (r == 0)
+    for (u32 s = 0; s < W; s++) {
+      roff[s] = total;
+      rcnt[s] = nreads[s];
+      total += nreads[s];
+    }
+  if ((rc = ensure(c, c->xg_buf, (total + 1) * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->or_tmp, total + 16))) return rc;
+  XC(xc_a2av(cm, c->seeds.p, soff, scnt, c->xg_buf.p, roff, rcnt, 8 * NW, c->stream));
+  XC(xc_a2av(cm, c->seed_valid.p, soff, scnt, c->or_tmp.p, roff, rcnt, 1, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // ---- structure on rank 0; its verdict and sizes to everybody
+  u64 meta[5] = {0, 0, 0, 0, 0};  // status, table slots, junctions, straights, nodes
+  if (r == 0) {
+    meta[0] = (u64)graph_structure<NW>(c, (const u64*)c->xg_buf.p, (const uint8_t*)c->or_tmp.p, total, est);
+    meta[1] = c->g_cap;
+    meta[2] = c->gstats_.n_junctions;
+    meta[3] = c->gstats_.n_straights;
+    meta[4] = c->gstats_.n_nodes;
+  }
+  XC(xc_allreduce(cm, meta, 5, 1, c->stream));
+  if (meta[0]) return r == 0 ? (int)meta[0] : fail(c, (int)meta[0], "the rank that builds the graph failed");
+  if (r != 0) {
+    if ((rc = graph_alloc_table<NW>(c, meta[1]))) return rc;
+    c->gstats_ = p3_graph_stats{};
+    c->gstats_.n_junctions = meta[2];
+    c->gstats_.n_straights = meta[3];
+    c->gstats_.n_nodes = meta[4];
+  }
+  {  // ---- the node table: rank 0 -> every rank
+    u64 so[P3_MAX_RANKS] = {0}, sc[P3_MAX_RANKS] = {0}, ro[P3_MAX_RANKS] = {0}, rn[P3_MAX_RANKS] = {0};
+    if (r == 0)
+      for (u32 s = 1; s < W; s++) sc[s] = meta[1];
+    else
+      rn[0] = meta[1];
+    DevBuf* kbuf[4] = {&c->g_klo, &c->g_khi, &c->g_k2, &c->g_k3};
+    // (a rank sends from and receives into different halves of the call: rank 0 only sends, the others only receive)
+    for (int j = 0; j < NW; j++) XC(xc_a2av(cm, kbuf[j]->p, so, sc, kbuf[j]->p, ro, rn, 8, c->stream));
+    XC(xc_a2av(cm, c->g_info.p, so, sc, c->g_info.p, ro, rn, 4, c->stream));
+    XC(xc_a2av(cm, c->g_nid.p, so, sc, c->g_nid.p, ro, rn, 4, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  // ---- coverage of every rank's reads, summed
+  if ((rc = graph_coverage<NW>(c))) return rc;
+  if (W > 1) {
+    struct Part {
+      DevBuf* buf;
+      u64 n;
+    } parts[2] = {{&c->g_jcov, (meta[2] + 1) * 9}, {&c->g_jtcov, 2 * meta[3] + 2}};
+    for (const Part& pt : parts) {
+      if ((rc = ensure(c, c->or_tmp, (u64)W * pt.n * 4))) return rc;
+      XC(xc_allgather(cm, pt.buf->p, c->or_tmp.p, pt.n * 4, c->stream));
+      LAUNCH(c, "k_dbg_sum_rows", k_dbg_sum_rows, grid_for(pt.n, 256, 1u << 30), 256, (const u32*)c->or_tmp.p, W, pt.n,
+             (u32*)pt.buf->p);
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+  }
+#undef XC
+  if (r != 0) return P3_OK;
+  return graph_links<NW>(c);
 }
 
 }  // namespace
 
 extern "C" {
+
+int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
+  if (!c || !cm) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "p3_mr_build_graph before p3_mr_run_pass");
+  if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  switch (nw_of(c->k)) {
+    case 1: rc = mr_build_graph_t<1>(c, cm); break;
+    case 2: rc = mr_build_graph_t<2>(c, cm); break;
+    case 3: rc = mr_build_graph_t<3>(c, cm); break;
+    default: rc = mr_build_graph_t<4>(c, cm); break;
+  }
+  if (rc) xc_abort(cm);
+  return rc;
+}
 
 int p3_build_graph(p3_ctx* c) {
   if (!c) return P3_EBADARG;

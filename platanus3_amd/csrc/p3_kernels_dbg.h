@@ -547,3 +547,12 @@ static __global__ void __launch_bounds__(256) k_dbg_edges(DbgTab t, DbgParams p,
     }
   }
 }
+
+// out[i] = sum over `rows` copies of in[row * n + i] (the ranks' coverage counters of a sharded job)
+static __global__ void __launch_bounds__(256) k_dbg_sum_rows(const u32* __restrict__ in, u32 rows, u64 n, u32* __restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 s = 0;
+  for (u32 r = 0; r < rows; r++) s += in[(u64)r * n + i];
+  out[i] = s;
+}

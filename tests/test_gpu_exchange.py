@@ -192,6 +192,74 @@ def test_run_pass_in_groups(oracle, procs, v, k, gate):
     _check_union(oracle, b, o, k, m, H, results)
 
 
+@pytest.mark.parametrize("case_name,procs,v", [("synth2000_k31", 1, 4), ("synth3000_k51", 2, 2), ("long40_k63", 1, 2),
+                                                ("wide:synth1500_k101", 1, 4), ("wide:dense3000_k80", 2, 2)])
+def test_sharded_graph_equals_reference_gfa(tmp_path, case_name, procs, v):
+    """p3_mr_run_pass + p3_mr_build_graph over procs x v ranks (threads on this one GPU): rank 0's GFA against the REAL
+    reference's for the union of the reads (canonical form), JointInfo::coverage included -- one- to four-word keys"""
+    import gzip
+    import hashlib
+    import json
+    import os
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    wide = case_name.startswith("wide:")
+    name = case_name.split(":")[-1]
+    prefix = "dbgw_" if wide else "dbg_"
+    case = [c for c in json.load(open(os.path.join(golden, prefix + "cases.json"))) if c["name"] == name][0]
+    z = np.load(os.path.join(golden, prefix + name + "_reads.npz"))
+    b, o = z["bases"], z["offsets"]
+    k, m, H = case["k"], case["m"], case["H"]
+    V = procs * v
+    n_reads = o.size - 1
+    cuts = [n_reads * i // V for i in range(V + 1)]
+    pw = PtrWorld(procs)
+    outers = [capi.Comm.callbacks(p, procs, *pw.callbacks(p)) if procs > 1 else None for p in range(procs)]
+    groups = [capi.Group(v, outers[p]) for p in range(procs)]
+    out, errors = {}, []
+
+    def worker(p, i):
+        r = p * v + i
+        try:
+            comm = capi.Comm.member(groups[p], i)
+            ctx = capi.Context(0)
+            a, e = cuts[r], cuts[r + 1]
+            ctx.load_reads(b[int(o[a]):int(o[e])], o[a:e + 1] - o[a], min_len=k)
+            ctx.mr_run_pass(comm, k, m, H)
+            ctx.mr_build_graph(comm)
+            if r == 0:
+                path = os.path.join(str(tmp_path), "g.gfa")
+                ctx.write_gfa(path)
+                out["gfa"] = open(path).read()
+                out["stats"] = ctx.graph_stats()
+                out["joints"] = ctx.joint_coverage()
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            pw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(p, i)) for p in range(procs) for i in range(v)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in groups:
+        g.close()
+    for c in outers:
+        if c is not None:
+            c.close()
+    assert not errors, errors
+    assert out["stats"]["n_junctions"] == case["n_junctions"] and out["stats"]["n_straights"] == case["n_straights"]
+    ls = canon_lines(*canonical(out["gfa"]))
+    with gzip.open(os.path.join(golden, prefix + name + ".canon.gz"), "rt") as f:
+        assert ls == f.read().split("\n")
+    jl = ["%s\t%d" % (a, c) for a, c in out["joints"]]
+    jg = case["joints"] if wide else json.load(open(os.path.join(golden, "dbg_joints.json")))[name]
+    assert len(jl) == jg["n"] and hashlib.sha256("\n".join(jl).encode()).hexdigest() == jg["sha256"]
+
+
 def test_group_member_failure_does_not_hang():
     """a member that fails (no reads loaded) aborts the group: the other member returns an error instead of waiting"""
     g = capi.Group(2, None)
