@@ -9,7 +9,8 @@
 //             -L<repo>/platanus3_amd/csrc -lplatanus3_amd -Wl,-rpath,<repo>/platanus3_amd/csrc -pthread -o platanus3
 //
 // The stages hand their results on in HBM (AssembleResident); PLATANUS3_MATERIALISE=1 runs the reference-typed
-// Assemble<B> of the shim instead (same outputs; seconds of host time for the STL containers).
+// Assemble<B> of the shim instead (same outputs; seconds of host time for the STL containers); PLATANUS3_GPUS=N shards the
+// run over N GPUs of the node (AssembleSharded: one thread and one RCCL rank per GPU, same GFA).
 //
 // What differs from the reference binary, on purpose: every k in [21,128] is dispatched (its switch has only 21, 25,
 // 63 and 101 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
@@ -35,7 +36,12 @@ struct Run {
     // PLATANUS3_MATERIALISE=1: go through the reference-typed containers (KmerCount, BF<bitset<2k>>, the graph's
     // maps) of Assemble<B>, as a caller written against them would; default: everything stays on the device
     const char* mat = std::getenv("PLATANUS3_MATERIALISE");
-    const int status = (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
+    // PLATANUS3_GPUS=N: the same run sharded over N GPUs of this node (the reference's option string "i:m:k:t:" has no
+    // room for it; -t stays the thread count it ignores for these stages)
+    const char* gpus = std::getenv("PLATANUS3_GPUS");
+    const int n_gpus = gpus && *gpus ? std::atoi(gpus) : 0;
+    const int status = n_gpus > 0 ? AssembleSharded(reads, opt, log, n_gpus)
+                       : (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
     if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..128)\n";
     log.WriteLog("finish");
     return status == 0 ? 0 : 3;

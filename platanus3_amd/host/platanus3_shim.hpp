@@ -38,6 +38,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -623,6 +624,77 @@ inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& lo
   logging.WriteLog("de bruijn graph loaded");
   logging.WriteLog("count node coverage");  // (accumulated by p3_build_graph)
   p3shim::check(ctx, p3_write_gfa(ctx, "./de_bruijn_graph.gfa"), "p3_write_gfa");
+  return 0;
+}
+
+// The same over several GPUs of this node (no counterpart in the single-process reference): the
+// ReadSet is sharded by iteration order, one host thread, one context and one RCCL rank per GPU; p3_mr_run_pass is
+// CountShortKmer + MakeBF over all shards, p3_mr_build_graph the de Bruijn stage (structure on rank 0, coverage of every
+// shard summed); rank 0 writes the GFA.  Same log lines as Assemble.  n_gpus = 1 is AssembleResident through the same path.
+inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& logging, int n_gpus) {
+  if (options.kmer_length < 21 || options.kmer_length > 128) return 1;
+  if (n_gpus < 1 || n_gpus > p3_device_count() || 1024 % n_gpus != 0)
+    throw std::invalid_argument("AssembleSharded: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(p3_device_count()) +
+                                " present (the count must divide 1024)");
+  logging.WriteLog("Assemble");
+  const uint32_t k = (uint32_t)options.kmer_length;
+  // shards of the ReadSet, flat (bases + offsets), by iteration order
+  const size_t n = input_reads.reads.size();
+  std::vector<std::string> bases((size_t)n_gpus);
+  std::vector<std::vector<uint64_t>> offs((size_t)n_gpus, std::vector<uint64_t>(1, 0));
+  {
+    size_t i = 0;
+    for (const auto& kv : input_reads.reads) {
+      const size_t r = i++ * (size_t)n_gpus / (n ? n : 1);
+      bases[r] += kv.second;
+      offs[r].push_back(bases[r].size());
+    }
+  }
+  uint8_t id[P3_COMM_ID_BYTES];
+  if (p3_comm_unique_id(id) != P3_OK) throw std::runtime_error("AssembleSharded: librccl cannot be opened");
+  std::vector<int> status((size_t)n_gpus, 0);
+  std::vector<std::string> what((size_t)n_gpus);
+  uint64_t n_seeds_total = 0;
+  std::mutex mu;
+  auto work = [&](int r) {
+    p3_ctx* ctx = nullptr;
+    p3_comm* comm = nullptr;
+    int rc = p3_create(&ctx, r);
+    if (!rc) rc = p3_comm_create_rccl(&comm, id, (uint32_t)r, (uint32_t)n_gpus, r);
+    if (!rc) rc = p3_load_reads(ctx, bases[(size_t)r].data(), offs[(size_t)r].data(), offs[(size_t)r].size() - 1, k);
+    if (!rc) rc = p3_mr_run_pass(ctx, comm, k, options.filter_size, options.num_hashes);
+    if (!rc) {
+      p3_bloom_stats bs;
+      if (p3_get_bloom_stats(ctx, &bs) == P3_OK) {
+        std::vector<uint64_t> keys((bs.n_seed_reads ? bs.n_seed_reads : 1) * (uint64_t)((2 * k + 63) / 64));
+        uint64_t ns = 0;
+        if (p3_export_seeds(ctx, keys.data(), bs.n_seed_reads ? bs.n_seed_reads : 1, &ns) == P3_OK) {
+          std::lock_guard<std::mutex> lk(mu);
+          n_seeds_total += ns;  // (per-rank sets: a seed that two shards share counts twice in this log line)
+        }
+      }
+    }
+    if (!rc) rc = p3_mr_build_graph(ctx, comm);
+    if (!rc && r == 0) rc = p3_write_gfa(ctx, "./de_bruijn_graph.gfa");
+    if (rc) what[(size_t)r] = ctx ? p3_last_error(ctx) : "p3_create failed";
+    status[(size_t)r] = rc;
+    if (comm) p3_comm_destroy(comm);
+    if (ctx) p3_destroy(ctx);
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < n_gpus; r++) th.emplace_back(work, r);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < n_gpus; r++)
+    if (status[(size_t)r])
+      throw std::runtime_error("AssembleSharded: rank " + std::to_string(r) + ": " + what[(size_t)r] + " (status " +
+                               std::to_string(status[(size_t)r]) + ")");
+  logging.WriteLog("counted short kmer");
+  logging.WriteLog("bloom filter loaded");
+  logging.WriteLog("get seed kmer");
+  logging.WriteLog("seed kmer num= " + std::to_string(n_seeds_total));
+  logging.WriteLog("start graph extention");
+  logging.WriteLog("de bruijn graph loaded");
+  logging.WriteLog("count node coverage");
   return 0;
 }
 

@@ -186,6 +186,36 @@ def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synth2000_k31", "wide:synth1500_k101"])
+def test_command_line_sharded_path(tmp_path_factory, tmp_path, name):
+    """PLATANUS3_GPUS=1: the run goes through AssembleSharded -- one thread and one REAL RCCL rank per GPU (the box has
+    one), p3_mr_run_pass + p3_mr_build_graph -- and writes the reference's GFA; more GPUs than present: exit status 3."""
+    import gzip
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    wide = name.startswith("wide:")
+    nm = name.split(":")[-1]
+    prefix = "dbgw_" if wide else "dbg_"
+    case = [c for c in json.load(open(os.path.join(GOLDEN, prefix + "cases.json"))) if c["name"] == nm][0]
+    exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
+    z = np.load(os.path.join(GOLDEN, prefix + nm + "_reads.npz"))
+    b, off = z["bases"], z["offsets"]
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(off.size - 1):
+            f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
+    args = [exe, "-i", fa, "-k", str(case["k"]), "-t", "1"] + (["-m", str(case["m"])] if case["H"] == 10 else [])
+    subprocess.check_call(args, cwd=str(tmp_path), timeout=180, env=dict(os.environ, PLATANUS3_GPUS="1"))
+    ls = canon_lines(*canonical(open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read()))
+    with gzip.open(os.path.join(GOLDEN, prefix + nm + ".canon.gz"), "rt") as f:
+        assert ls == f.read().split("\n")
+    log = open(os.path.join(str(tmp_path), "platanus3.log")).read()
+    assert "seed kmer num= " in log and log.rstrip().endswith("finish")
+    r = subprocess.run(args, cwd=str(tmp_path), timeout=180, env=dict(os.environ, PLATANUS3_GPUS="64"), capture_output=True)
+    assert r.returncode == 3 and b"GPUs asked for" in r.stderr
+
+
+@pytest.mark.gpu
 def test_command_line_fastq_and_multiline_fasta(tmp_path_factory, tmp_path):
     """The same reads as a FASTQ file (four lines per record) and as a FASTA file with the sequences wrapped at 60
     columns give the reference's GFA too (row T1: both loaders feed the same ReadSet)."""
