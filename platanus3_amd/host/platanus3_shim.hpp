@@ -654,7 +654,7 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
   if (p3_comm_unique_id(id) != P3_OK) throw std::runtime_error("AssembleSharded: librccl cannot be opened");
   std::vector<int> status((size_t)n_gpus, 0);
   std::vector<std::string> what((size_t)n_gpus);
-  uint64_t n_seeds_total = 0;
+  std::set<std::array<uint64_t, 4>> all_seeds;  // the union of the ranks' seed sets (the reference logs its size)
   std::mutex mu;
   auto work = [&](int r) {
     p3_ctx* ctx = nullptr;
@@ -669,8 +669,13 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
         std::vector<uint64_t> keys((bs.n_seed_reads ? bs.n_seed_reads : 1) * (uint64_t)((2 * k + 63) / 64));
         uint64_t ns = 0;
         if (p3_export_seeds(ctx, keys.data(), bs.n_seed_reads ? bs.n_seed_reads : 1, &ns) == P3_OK) {
+          const uint64_t nw = (2 * k + 63) / 64;
           std::lock_guard<std::mutex> lk(mu);
-          n_seeds_total += ns;  // (per-rank sets: a seed that two shards share counts twice in this log line)
+          for (uint64_t i = 0; i < ns; i++) {
+            std::array<uint64_t, 4> key = {0, 0, 0, 0};
+            for (uint64_t t = 0; t < nw; t++) key[t] = keys[i * nw + t];
+            all_seeds.insert(key);
+          }
         }
       }
     }
@@ -691,7 +696,7 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
   logging.WriteLog("counted short kmer");
   logging.WriteLog("bloom filter loaded");
   logging.WriteLog("get seed kmer");
-  logging.WriteLog("seed kmer num= " + std::to_string(n_seeds_total));
+  logging.WriteLog("seed kmer num= " + std::to_string(all_seeds.size()));
   logging.WriteLog("start graph extention");
   logging.WriteLog("de bruijn graph loaded");
   logging.WriteLog("count node coverage");
