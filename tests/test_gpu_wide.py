@@ -221,3 +221,29 @@ def test_wide_graph_vs_oracle(oracle, tmp_path, k, n, L, m, H):
         assert ctx.joint_coverage() == oracle.dbg_joints((b, off), words, m, H, seeds, k)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("chunks", [2, 4])
+def test_wide_keys_over_position_chunks(oracle, tmp_path, chunks):
+    """the form of inputs beyond 2^30 window positions (the count stage works chunk by chunk and assembles S over the whole
+    stream) with four-word keys, forced on a small input: vector, seeds and graph against the oracle"""
+    from gfa_canon import canonical
+    k, m, H = 101, 1 << 22, 10
+    b, off = synth.reads(seed=95, total_reads=24000, read_len=250, sub_rate_ppm=5000)
+    ctx = capi.Context(0)
+    try:
+        ctx.set_option("chunks", chunks)
+        ctx.load_reads(b, off, min_len=k)
+        ctx.run_pass(k, m, H)
+        assert ctx.get_info("chunks") == chunks
+        keys, counts = oracle.count_short((b, off), min_len=k)
+        words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+        assert np.array_equal(ctx.export_bloom(), words)
+        assert [capi.decode_key(x, k) for x in ctx.export_seeds()] == seeds
+        st = ctx.build_graph()
+        path = os.path.join(str(tmp_path), "g.gfa")
+        ctx.write_gfa(path)
+        want, ost = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
+        assert st["n_junctions"] == ost["junctions"] and canonical(open(path).read()) == canonical(want)
+    finally:
+        ctx.close()
