@@ -54,6 +54,7 @@ int main(int argc, char** argv) {
     int rc = p3_create(&ctx, (int)r);
     if (!rc) rc = p3_comm_create_rccl(&comm, id, r, N, (int)r);
     if (!rc) rc = p3_load_reads(ctx, bases.data(), offs.data(), per, k);
+    if (!rc && N > 1) rc = p3_mr_reshard_reads(ctx, comm);  // one all-to-all of the reads: genomic neighbourhoods onto one GPU
     if (!rc) rc = p3_mr_run_pass(ctx, comm, k, m, H);
     const auto t0 = std::chrono::steady_clock::now();
     if (!rc) rc = p3_mr_run_pass(ctx, comm, k, m, H);

@@ -662,6 +662,7 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
     int rc = p3_create(&ctx, r);
     if (!rc) rc = p3_comm_create_rccl(&comm, id, (uint32_t)r, (uint32_t)n_gpus, r);
     if (!rc) rc = p3_load_reads(ctx, bases[(size_t)r].data(), offs[(size_t)r].data(), offs[(size_t)r].size() - 1, k);
+    if (!rc && n_gpus > 1) rc = p3_mr_reshard_reads(ctx, comm);  // reads of one genomic neighbourhood onto one GPU
     if (!rc) rc = p3_mr_run_pass(ctx, comm, k, options.filter_size, options.num_hashes);
     if (!rc) {
       p3_bloom_stats bs;

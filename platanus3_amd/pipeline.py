@@ -219,6 +219,16 @@ class Pipeline:
     def synchronize(self):
         pass  # every C-ABI call returns with its stream drained
 
+    def reshard(self):
+        """a sharded job: deal the reads out once more by genomic neighbourhood (p3_mr_reshard_reads: one all-to-all of the
+        reads before the passes; no result depends on which rank holds a read, the work per rank does).  Returns whether
+        it happened (the in-library exchange is needed)."""
+        if self.native is None:
+            return False
+        self.ctx.mr_reshard_reads(self.native)
+        self.resharded = True
+        return True
+
     # ---- the pass ---------------------------------------------------------------------------------------
     def run_pass(self, k, m, H):
         if not self.protocol:
@@ -309,7 +319,9 @@ class Pipeline:
         self.ctx.set_option("drop_hints", 1)
 
     def parallelism(self):
-        return "reads sharded by index x%d%s" % (self.world, ", exchange inside the library (RCCL)" if self.native is not None else "")
+        return "reads sharded by index x%d%s%s" % (
+            self.world, ", then re-sharded by read minimizer" if getattr(self, "resharded", False) else "",
+            ", exchange inside the library (RCCL)" if self.native is not None else "")
 
     def close(self):
         if self.native is not None:
@@ -524,6 +536,10 @@ class VirtualRanks:
     def run_pass(self, k, m, H):
         self._each(lambda p: p.run_pass(k, m, H))
 
+    def reshard(self):
+        self.resharded = all(self._each(lambda p: p.reshard()))
+        return self.resharded
+
     def drop_hints(self):
         for p in self.pipes:
             p.drop_hints()
@@ -538,8 +554,9 @@ class VirtualRanks:
         return {"n_solid": self._each(lambda p: p.comm.all_reduce_sum(p.ctx.count_stats()["n_solid"]))[0]}
 
     def parallelism(self):
-        return "reads sharded by index x%d (%d protocol ranks per GPU%s)" % (
-            self.world, self.v, ", exchange inside the library" if self.native_group is not None else "")
+        return "reads sharded by index x%d%s (%d protocol ranks per GPU%s)" % (
+            self.world, ", then re-sharded by read minimizer" if getattr(self, "resharded", False) else "", self.v,
+            ", exchange inside the library" if self.native_group is not None else "")
 
     def close(self):
         for p in self.pipes:

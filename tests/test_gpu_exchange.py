@@ -260,6 +260,71 @@ def test_sharded_graph_equals_reference_gfa(tmp_path, case_name, procs, v):
     assert len(jl) == jg["n"] and hashlib.sha256("\n".join(jl).encode()).hexdigest() == jg["sha256"]
 
 
+@pytest.mark.parametrize("procs,v,k", [(1, 4, 31), (2, 2, 45), (1, 8, 31), (2, 4, 101)])
+def test_resharded_reads_give_the_same_results(oracle, procs, v, k):
+    """p3_mr_reshard_reads: every read moves to rank (its smallest canonical-21-mer hash) mod N before the passes.  The read
+    multiset is conserved and count table, vector and seed set equal the oracle's for the union -- ragged input: reads
+    shorter than 21, of unknown characters only, empty ones."""
+    V = procs * v
+    rng = np.random.RandomState(7)
+    b0, o0 = synth.reads(seed=65, total_reads=12000, read_len=200, sub_rate_ppm=4000)
+    reads = []
+    for i in range(12000):
+        r = bytearray(b0[int(o0[i]):int(o0[i + 1])].tobytes())
+        L = [200, 150, 101, 30, 20, 0, 200, 180][i % 8]
+        r = r[:L]
+        if i % 13 == 0 and L:
+            r[rng.randint(0, L)] = ord("N")
+        if i % 97 == 0:
+            r = bytearray(b"N" * L)
+        reads.append(bytes(r))
+    b = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    o = np.zeros(len(reads) + 1, np.uint64)
+    o[1:] = np.cumsum([len(r) for r in reads])
+    n_reads = len(reads)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    cuts = [n_reads * i // V for i in range(V + 1)]
+    pw = PtrWorld(procs)
+    outers = [capi.Comm.callbacks(p, procs, *pw.callbacks(p)) if procs > 1 else None for p in range(procs)]
+    groups = [capi.Group(v, outers[p]) for p in range(procs)]
+    results, sizes, errors = [None] * V, [None] * V, []
+
+    def worker(p, i):
+        r = p * v + i
+        try:
+            comm = capi.Comm.member(groups[p], i)
+            ctx = capi.Context(0)
+            a, e = cuts[r], cuts[r + 1]
+            ctx.load_reads(b[int(o[a]):int(o[e])], o[a:e + 1] - o[a], min_len=k)
+            ctx.mr_reshard_reads(comm)
+            ctx.mr_run_pass(comm, k, m, H)
+            ctx.mr_run_pass(comm, k, m, H)
+            keys, counts = ctx.export_counts()
+            results[r] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            sizes[r] = ctx.count_stats()["n_windows"]
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            pw.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(p, i)) for p in range(procs) for i in range(v)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in groups:
+        g.close()
+    for c in outers:
+        if c is not None:
+            c.close()
+    assert not errors, errors
+    _check_union(oracle, b, o, k, m, H, results)
+    # every valid window is still somewhere, exactly once
+    assert sum(sizes) == sum(max(0, len(r) - 20) for r in reads if len(r) >= k)
+    assert min(sizes) > 0.5 * sum(sizes) / V  # and the deal is even enough
+
+
 def test_group_member_failure_does_not_hang():
     """a member that fails (no reads loaded) aborts the group: the other member returns an error instead of waiting"""
     g = capi.Group(2, None)

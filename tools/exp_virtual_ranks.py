@@ -1,5 +1,5 @@
 """Time pipeline.VirtualRanks (several protocol ranks on ONE GPU) against the single-context pass on the same reads.
-usage: python tools/exp_virtual_ranks.py [total_reads] [per_rank] [k]"""
+usage: [RESHARD=1] [VR_STEPS=n] python tools/exp_virtual_ranks.py [total_reads] [per_rank] [k]"""
 import os
 import sys
 import time
@@ -14,6 +14,10 @@ v = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
 m, H = bloom_sizing(n * 150, k)
 vr = VirtualRanks(device=0, rank=0, world=1, per_rank=v, seed=1, total_reads=n, first_read=0, n_reads=n)
+if os.environ.get("RESHARD", "0") == "1":
+    t0 = time.perf_counter()
+    vr.reshard()
+    print("re-sharded by read minimizer in %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
 print("form:", vr.parallelism(), flush=True)
 for step in range(int(os.environ.get("VR_STEPS", "4"))):
     t0 = time.perf_counter()
