@@ -16,6 +16,24 @@ total = per * world
 m, H = bloom_sizing(total * 150, k)
 lw = LoopbackWorld(world, serialize=True)
 out = [None] * world
+# SHARD=minimizer: the reads dealt out by a read-level minimizer (what p3_mr_reshard_reads does; here on the host, because
+# this harness drives the Python form of the protocol) instead of by index
+shards = None
+if os.environ.get("SHARD", "") == "minimizer":
+    import ctypes as C, subprocess
+    import numpy as np
+    so = "/tmp/libshardkeys.so"
+    subprocess.check_call(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", os.path.join(R, "tools", "shard_keys.c"), "-o", so])
+    lib = C.CDLL(so)
+    ball, oall = synth.reads(seed=2, total_reads=total, read_len=150)
+    keys = np.zeros(total, np.uint64)
+    lib.shard_keys(ball.ctypes.data_as(C.c_void_p), oall.ctypes.data_as(C.c_void_p), C.c_uint64(total), keys.ctypes.data_as(C.c_void_p))
+    owner = (keys % np.uint64(world)).astype(np.int64)
+    r2d = ball.reshape(total, 150)
+    shards = []
+    for r_ in range(world):
+        idx = np.nonzero(owner == r_)[0]
+        shards.append((np.ascontiguousarray(r2d[idx]).reshape(-1), np.arange(idx.size + 1, dtype=np.uint64) * 150))
 def worker(r):
     lw.begin(r)
     try:
@@ -25,7 +43,7 @@ def worker(r):
 
 
 def _worker(r):
-    b, o = synth.reads(seed=2, total_reads=total, first_read=r * per, n_reads=per, read_len=150)
+    b, o = shards[r] if shards is not None else synth.reads(seed=2, total_reads=total, first_read=r * per, n_reads=per, read_len=150)
     pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
     pipe.ctx.set_option('mr_aggregate', agg)
     pipe.load_reads(b, o, min_len=k)

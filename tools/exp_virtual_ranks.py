@@ -23,6 +23,16 @@ for step in range(int(os.environ.get("VR_STEPS", "4"))):
     t0 = time.perf_counter()
     vr.run_pass(k, m, H)
     print("virtual ranks pass %d: %.1f ms" % (step, (time.perf_counter() - t0) * 1e3), flush=True)
+if os.environ.get("VR_PROFILE", "0") == "1":   # per-kernel times of rank 0 (events around every launch; the other ranks share the GPU)
+    c0 = vr.pipes[0].ctx
+    c0.reset_kernel_stats()
+    c0.set_profiling(True)
+    vr.run_pass(k, m, H)
+    c0.set_profiling(False)
+    st = c0.kernel_stats()
+    print("rank 0 kernels: " + ", ".join("%s=%.2f(%d)" % (nm, v_["total_ms"], v_["launches"])
+                                         for nm, v_ in sorted(st.items(), key=lambda kv: -kv[1]["total_ms"])[:16]), flush=True)
+    print("rank 0 kernel total %.2f ms" % sum(v_["total_ms"] for v_ in st.values()), flush=True)
 dv, pv = vr.global_distinct(), vr.passing_kmers()
 vr.close()
 pipe = Pipeline(device=0)
