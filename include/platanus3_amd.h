@@ -318,6 +318,14 @@ int p3_mr_run_pass(p3_ctx* ctx, p3_comm* comm, uint32_t k, uint64_t m_bits, uint
  * owns its new reads; read order inside a rank changes, per-read outputs such as the seeds keep their union).
  * Measured with 8 ranks: locally distinct passing k-mers per rank 74.9 M -> 35.5 M, pass 164 -> 98 ms. */
 int p3_mr_reshard_reads(p3_ctx* ctx, p3_comm* comm);
+/* The same idea for ONE context whose input is larger than one partition (more than 2^30 window positions: the stages
+ * then work on position chunks): the reads are put in the ORDER of their shard key's group, so that a chunk holds few
+ * genomic neighbourhoods at full coverage instead of all of them at 1/chunks of it.  n_groups = 0: as many groups as
+ * the input has chunks.  Optional, once per input, after p3_load_reads*; results do not change.  (Measured on one
+ * MI355X: no gain as the stages are tuned today -- 16 M reads 72.5 -> 77 ms, 50 M reads 296 -> 294 ms per pass: the
+ * collected k-mer list halves, but a chunk's k-mer sets then take the plain form with four readers per bucket instead of
+ * the second-level partition.  Kept for experiments; the sharded form, p3_mr_reshard_reads, is where the idea pays.) */
+int p3_group_reads(p3_ctx* ctx, uint32_t n_groups);
 /* The de Bruijn stage of a sharded job, after p3_mr_run_pass (every rank calls it): rank 0 gathers the ranks' seeds and
  * builds the structure (MakeDBG), the node table goes to every rank, every rank counts the coverage of ITS reads against
  * it (CountNodeCoverage), the counters are summed, rank 0 emits the links.  Afterwards rank 0 holds the graph

@@ -112,6 +112,7 @@ def load(build=False):
     L.p3_mr_run_pass.argtypes = [vp, vp, C.c_uint32, u64, C.c_uint32]
     L.p3_mr_build_graph.argtypes = [vp, vp]
     L.p3_mr_reshard_reads.argtypes = [vp, vp]
+    L.p3_group_reads.argtypes = [vp, C.c_uint32]
     L.p3_write_gfa.argtypes = [vp, C.c_char_p]
     L.p3_mr_config.argtypes = [vp, u32, u32]
     L.p3_mr_count_partition.argtypes = [vp]
@@ -305,6 +306,10 @@ class Context:
         """one rank's share of the sharded pass with the exchanges INSIDE the library (p3_exchange.hip)"""
         self._chk(self.L.p3_mr_run_pass(self.h, comm.h, k, m, H))
         self.k, self.m, self.H = k, m, H
+
+    def group_reads(self, n_groups=0):
+        """one context, large input: put the reads in the order of their shard key's group (once, after load_reads)"""
+        self._chk(self.L.p3_group_reads(self.h, n_groups))
 
     def mr_reshard_reads(self, comm):
         """deal the reads of a sharded job out once more, by genomic neighbourhood (every rank, once, before the passes)"""

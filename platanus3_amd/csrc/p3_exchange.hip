@@ -501,8 +501,119 @@ int p3_comm_destroy(p3_comm* cm) {
 }
 
 
-// Deal the reads of a sharded job out once more, by genomic neighbourhood (p3_kernels_shard.h).  One-time work before the
-// passes: the bookkeeping (which read goes where) is done on the host from two small per-read arrays.
+// ---- reads grouped by genomic neighbourhood (p3_kernels_shard.h) ---------------------------------------------------------
+// The context's reads, copied into `grouped` so that the reads of group g = (shard key mod W) are contiguous (original
+// order inside a group); lens = their lengths in the new order, cnt_* / off_* = reads and bases per group.  One-time work:
+// the bookkeeping is done on the host from two small per-read arrays.
+static int group_reads_by_key(p3_ctx* c, u32 W, DevBuf& grouped, std::vector<u32>& lens, u64* cnt_reads, u64* cnt_bases,
+                              u64* off_reads, u64* off_bases) {
+  int rc;
+  const u64 n = c->n_reads;
+  DevBuf d_owner, d_len, d_pos;
+  auto done = [&](int code) {
+    release(d_owner);
+    release(d_len);
+    release(d_pos);
+    return code;
+  };
+  if ((rc = ensure(c, d_owner, (n + 1) * 4)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
+      (rc = ensure(c, grouped, c->n_bases + 64)))
+    return done(rc);
+  if (n) {
+    hipLaunchKernelGGL(k_shard_keys, dim3(grid_for(n, 256, 1u << 30)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n, W,
+                       (u32*)d_owner.p, (u32*)d_len.p);
+    if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "k_shard_keys launch"));
+  }
+  std::vector<u32> owner(n), len(n);
+  if (n && (hipMemcpyAsync(owner.data(), d_owner.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(len.data(), d_len.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
+    return done(fail(c, P3_EHIP, "shard keys copy"));
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, P3_EHIP, "shard keys sync"));
+  for (u32 d = 0; d < W; d++) cnt_reads[d] = cnt_bases[d] = 0;
+  for (u64 i = 0; i < n; i++) {
+    cnt_reads[owner[i]]++;
+    cnt_bases[owner[i]] += len[i];
+  }
+  off_reads[0] = off_bases[0] = 0;
+  for (u32 d = 0; d < W; d++) {
+    off_reads[d + 1] = off_reads[d] + cnt_reads[d];
+    off_bases[d + 1] = off_bases[d] + cnt_bases[d];
+  }
+  std::vector<u64> pos(n);
+  lens.assign(n, 0);
+  {
+    std::vector<u64> cur_r(off_reads, off_reads + W), cur_b(off_bases, off_bases + W);
+    for (u64 i = 0; i < n; i++) {
+      const u32 d = owner[i];
+      pos[i] = cur_b[d];
+      lens[cur_r[d]++] = len[i];
+      cur_b[d] += len[i];
+    }
+  }
+  if (n) {
+    if (hipMemcpyAsync(d_pos.p, pos.data(), n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      return done(fail(c, P3_EHIP, "layout copy"));
+    hipLaunchKernelGGL(k_move_reads, dim3(grid_for(n * 64, 256, 1u << 16)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
+                       (const u64*)d_pos.p, (uint8_t*)grouped.p);
+    if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "k_move_reads launch"));
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, P3_EHIP, "move reads"));  // (pos is a host vector)
+  return done(P3_OK);
+}
+
+// the context takes `bases` (n_new reads of the given lengths, back to back) as its reads
+static int install_reads(p3_ctx* c, DevBuf& bases, const std::vector<u32>& lens) {
+  const u64 n_new = lens.size();
+  std::vector<u64> offs(n_new + 1);
+  offs[0] = 0;
+  u64 hw = 0;
+  for (u64 i = 0; i < n_new; i++) {
+    offs[i + 1] = offs[i] + lens[i];
+    if (lens[i] >= c->min_len && lens[i] >= P3_SHORTK) hw += lens[i] - (P3_SHORTK - 1);
+  }
+  DevBuf new_offsets;
+  int rc;
+  if ((rc = ensure(c, new_offsets, (n_new + 1) * 8))) return rc;
+  if (hipMemcpy(new_offsets.p, offs.data(), (n_new + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+    release(new_offsets);
+    return fail(c, P3_EHIP, "offsets copy");
+  }
+  release(c->owned_bases);
+  release(c->owned_offsets);
+  c->owned_bases = bases;
+  c->owned_offsets = new_offsets;
+  bases = DevBuf();
+  c->d_bases = (const uint8_t*)c->owned_bases.p;
+  c->d_offsets = (const u64*)c->owned_offsets.p;
+  const u32 min_len = c->min_len;
+  rc = set_reads_common(c, n_new, offs[n_new], min_len);
+  c->host_windows = hw;
+  return rc;
+}
+
+// One context, inputs beyond one partition: the same grouping applied to the ORDER of the reads (no exchange).  The count
+// and Bloom stages then work on position chunks that each hold few genomic neighbourhoods at full coverage instead of all
+// of them at 1/chunks of it, so a chunk's k-mer dedup removes what it is there to remove.
+int p3_group_reads(p3_ctx* c, uint32_t n_groups) {
+  if (!c) return P3_EBADARG;
+  if (!c->have_reads) return fail(c, P3_ESTATE, "p3_group_reads before p3_load_reads");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (n_groups == 0) {  // as many groups as the input will have position chunks (at least 2)
+    n_groups = 2;
+    while (n_groups < 64 && c->n_words * 32 / n_groups > (1ull << 30)) n_groups <<= 1;
+  }
+  if (n_groups > P3_MAX_RANKS) return fail(c, P3_EBADARG, "at most %d groups", P3_MAX_RANKS);
+  DevBuf grouped;
+  std::vector<u32> lens;
+  u64 cr[P3_MAX_RANKS], cb[P3_MAX_RANKS], orr[P3_MAX_RANKS + 1], ob[P3_MAX_RANKS + 1];
+  int rc = group_reads_by_key(c, n_groups, grouped, lens, cr, cb, orr, ob);
+  if (!rc) rc = install_reads(c, grouped, lens);
+  release(grouped);
+  return rc;
+}
+
+// Deal the reads of a sharded job out once more, by genomic neighbourhood: group by (shard key mod n_ranks), one variable
+// all-to-all of the bases and one of the lengths, install.
 int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
   if (!c || !cm) return P3_EBADARG;
   if (!c->have_reads) return fail(c, P3_ESTATE, "p3_mr_reshard_reads before p3_load_reads");
@@ -510,71 +621,19 @@ int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
   if (W > P3_MAX_RANKS) return fail(c, P3_EBADARG, "too many ranks");
   int rc;
   HIPCHK(c, hipSetDevice(c->device));
-#define COMM(expr)                                                \
-  do {                                                            \
-    if ((rc = (expr))) {                                          \
-      if (cm->group) cm->group->abort();                          \
-      return fail(c, rc, "%s", cm->err.c_str());                  \
-    }                                                             \
-  } while (0)
-  const u64 n = c->n_reads;
-  DevBuf d_owner, d_len, d_pos, d_send, d_sendlen, d_recvlen, new_bases, new_offsets;
-  auto cleanup = [&]() {
-    DevBuf* tmp[] = {&d_owner, &d_len, &d_pos, &d_send, &d_sendlen, &d_recvlen, &new_bases, &new_offsets};
-    for (DevBuf* b : tmp) release(*b);
-  };
+  DevBuf d_send, d_sendlen, d_recvlen, new_bases;
   auto bail = [&](int code) {
-    cleanup();
-    if (cm->group) cm->group->abort();
+    DevBuf* tmp[] = {&d_send, &d_sendlen, &d_recvlen, &new_bases};
+    for (DevBuf* b : tmp) release(*b);
+    if (code && cm->group) cm->group->abort();
     return code;
   };
-  if ((rc = ensure(c, d_owner, (n + 1) * 4)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
-      (rc = ensure(c, d_send, c->n_bases + 64)) || (rc = ensure(c, d_sendlen, (n + 1) * 4)))
-    return bail(rc);
-  if (n) {
-    hipLaunchKernelGGL(k_shard_keys, dim3(grid_for(n, 256, 1u << 30)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n, W,
-                       (u32*)d_owner.p, (u32*)d_len.p);
-    if (hipGetLastError() != hipSuccess) return bail(fail(c, P3_EHIP, "k_shard_keys launch"));
-  }
-  std::vector<u32> owner(n), len(n);
-  if (n && (hipMemcpyAsync(owner.data(), d_owner.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(len.data(), d_len.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
-    return bail(fail(c, P3_EHIP, "shard keys copy"));
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(c, P3_EHIP, "shard keys sync"));
-  // send layout: reads grouped by owner, original order inside a group
-  u64 cnt_reads[P3_MAX_RANKS] = {0}, cnt_bases[P3_MAX_RANKS] = {0}, off_reads[P3_MAX_RANKS + 1] = {0}, off_bases[P3_MAX_RANKS + 1] = {0};
-  for (u64 i = 0; i < n; i++) {
-    cnt_reads[owner[i]]++;
-    cnt_bases[owner[i]] += len[i];
-  }
-  for (u32 d = 0; d < W; d++) {
-    off_reads[d + 1] = off_reads[d] + cnt_reads[d];
-    off_bases[d + 1] = off_bases[d] + cnt_bases[d];
-  }
-  std::vector<u64> pos(n);
-  std::vector<u32> sendlen(n);
-  {
-    u64 cur_r[P3_MAX_RANKS], cur_b[P3_MAX_RANKS];
-    for (u32 d = 0; d < W; d++) {
-      cur_r[d] = off_reads[d];
-      cur_b[d] = off_bases[d];
-    }
-    for (u64 i = 0; i < n; i++) {
-      const u32 d = owner[i];
-      pos[i] = cur_b[d];
-      sendlen[cur_r[d]++] = len[i];
-      cur_b[d] += len[i];
-    }
-  }
-  if (n) {
-    if (hipMemcpyAsync(d_pos.p, pos.data(), n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(d_sendlen.p, sendlen.data(), n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-      return bail(fail(c, P3_EHIP, "send layout copy"));
-    hipLaunchKernelGGL(k_move_reads, dim3(grid_for(n * 64, 256, 1u << 16)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
-                       (const u64*)d_pos.p, (uint8_t*)d_send.p);
-    if (hipGetLastError() != hipSuccess) return bail(fail(c, P3_EHIP, "k_move_reads launch"));
-  }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(c, P3_EHIP, "move reads"));  // (pos / sendlen are host vectors)
+  std::vector<u32> sendlen;
+  u64 cnt_reads[P3_MAX_RANKS], cnt_bases[P3_MAX_RANKS], off_reads[P3_MAX_RANKS + 1], off_bases[P3_MAX_RANKS + 1];
+  if ((rc = group_reads_by_key(c, W, d_send, sendlen, cnt_reads, cnt_bases, off_reads, off_bases))) return bail(rc);
+  const u64 n = sendlen.size();
+  if ((rc = ensure(c, d_sendlen, (n + 1) * 4))) return bail(rc);
+  if (n && hipMemcpy(d_sendlen.p, sendlen.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(c, P3_EHIP, "lengths copy"));
   // what everybody sends me
   u64 rcnt_reads[P3_MAX_RANKS], rcnt_bases[P3_MAX_RANKS], roff_reads[P3_MAX_RANKS + 1] = {0}, roff_bases[P3_MAX_RANKS + 1] = {0};
   if ((rc = exchange_counts(c, cm, cnt_reads, rcnt_reads)) || (rc = exchange_counts(c, cm, cnt_bases, rcnt_bases))) return bail(rc);
@@ -583,38 +642,19 @@ int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
     roff_bases[s2 + 1] = roff_bases[s2] + rcnt_bases[s2];
   }
   const u64 n_new = roff_reads[W], b_new = roff_bases[W];
-  if ((rc = ensure(c, new_bases, b_new + 64)) || (rc = ensure(c, new_offsets, (n_new + 1) * 8)) || (rc = ensure(c, d_recvlen, (n_new + 1) * 4)))
-    return bail(rc);
-  COMM(comm_a2av(cm, d_send.p, off_bases, cnt_bases, new_bases.p, roff_bases, rcnt_bases, 1, c->stream));
-  COMM(comm_a2av(cm, d_sendlen.p, off_reads, cnt_reads, d_recvlen.p, roff_reads, rcnt_reads, 4, c->stream));
-#undef COMM
+  if ((rc = ensure(c, new_bases, b_new + 64)) || (rc = ensure(c, d_recvlen, (n_new + 1) * 4))) return bail(rc);
+  if ((rc = comm_a2av(cm, d_send.p, off_bases, cnt_bases, new_bases.p, roff_bases, rcnt_bases, 1, c->stream)) ||
+      (rc = comm_a2av(cm, d_sendlen.p, off_reads, cnt_reads, d_recvlen.p, roff_reads, rcnt_reads, 4, c->stream)))
+    return bail(fail(c, rc, "%s", cm->err.c_str()));
   std::vector<u32> rlen(n_new);
   if (n_new && hipMemcpyAsync(rlen.data(), d_recvlen.p, n_new * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
     return bail(fail(c, P3_EHIP, "lengths copy"));
   if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(c, P3_EHIP, "exchange sync"));
-  std::vector<u64> offs(n_new + 1);
-  offs[0] = 0;
-  u64 hw = 0;
-  for (u64 i = 0; i < n_new; i++) {
-    offs[i + 1] = offs[i] + rlen[i];
-    if (rlen[i] >= c->min_len && rlen[i] >= P3_SHORTK) hw += rlen[i] - (P3_SHORTK - 1);
-  }
-  if (offs[n_new] != b_new) return bail(fail(c, P3_ECOMM, "re-sharded reads: lengths and bases disagree"));
-  if (hipMemcpy(new_offsets.p, offs.data(), (n_new + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(c, P3_EHIP, "offsets copy"));
-  // the context owns its new reads
-  release(c->owned_bases);
-  release(c->owned_offsets);
-  c->owned_bases = new_bases;
-  c->owned_offsets = new_offsets;
-  new_bases = DevBuf();
-  new_offsets = DevBuf();
-  c->d_bases = (const uint8_t*)c->owned_bases.p;
-  c->d_offsets = (const u64*)c->owned_offsets.p;
-  const u32 min_len = c->min_len;
-  cleanup();
-  rc = set_reads_common(c, n_new, b_new, min_len);
-  c->host_windows = hw;
-  return rc;
+  u64 total = 0;
+  for (u32 L : rlen) total += L;
+  if (total != b_new) return bail(fail(c, P3_ECOMM, "re-sharded reads: lengths and bases disagree"));
+  rc = install_reads(c, new_bases, rlen);
+  return bail(rc);
 }
 
 static int run_pass_steps(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, uint32_t H);

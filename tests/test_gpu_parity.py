@@ -22,9 +22,10 @@ def seeds_as_strings(ctx):
     return [capi.decode_key(row, ctx.k) for row in ctx.export_seeds()]
 
 
-def run_and_compare(ctx, oracle, reads, k, m, H, expect=None):
+def run_and_compare(ctx, oracle, reads, k, m, H, expect=None, loaded=False):
     bases, offs = flat(reads) if not isinstance(reads, tuple) else reads
-    ctx.load_reads(bases, offs, min_len=k)
+    if not loaded:
+        ctx.load_reads(bases, offs, min_len=k)
     st = ctx.count_short()
     keys, counts = ctx.export_counts()
     if expect is None:
@@ -108,6 +109,27 @@ def test_empty_and_degenerate_inputs(ctx, oracle):
     # zero reads
     ctx.load_reads(np.zeros(1, np.uint8), np.zeros(1, np.uint64), min_len=21)
     assert ctx.count_short()["n_distinct"] == 0
+
+
+@pytest.mark.parametrize("chunks,groups", [(1, 4), (4, 0), (8, 8)])
+def test_grouped_reads_give_the_same_results(oracle, chunks, groups):
+    """p3_group_reads: the reads put in the order of their shard key's group (for inputs that are processed in position
+    chunks: a chunk then holds few genomic neighbourhoods at full coverage) -- every result unchanged"""
+    b0, o0 = synth.reads(seed=33, total_reads=24000, read_len=150)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(0, 151, size=24000)
+    b = np.concatenate([b0[int(o0[i]):int(o0[i]) + int(lens[i])] for i in range(24000)])
+    o = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    k = 31
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    try:
+        c.set_option("chunks", chunks)
+        c.load_reads(b, o, min_len=k)
+        c.group_reads(groups)
+        run_and_compare(c, oracle, (b, o), k, m, H, loaded=True)
+    finally:
+        c.close()
 
 
 def test_timings_and_byte_counters(ctx):

@@ -22,6 +22,8 @@ for kv in os.environ.get("P3_OPTS", "").split(","):   # e.g. P3_OPTS=kmer_split=
     if kv:
         c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 t0 = time.time(); c.load_reads(b, o, k); print("load %.1f s" % (time.time() - t0), flush=True)
+if os.environ.get("P3_GROUP", "0") != "0":   # reads put in the order of their shard key's group (p3_group_reads), once
+    t0 = time.time(); c.group_reads(int(os.environ["P3_GROUP"]) if os.environ["P3_GROUP"] != "1" else 0); print("group_reads %.2f s" % (time.time() - t0), flush=True)
 for i in range(int(os.environ.get('P3_PASSES', '2'))):
     t0 = time.perf_counter(); c.run_pass(k, m, H); dt = time.perf_counter() - t0
     nk = R * (L - k + 1)
