@@ -146,6 +146,7 @@ void forget_learnt(p3_ctx* c, bool new_reads) {
   c->sbits_epoch = ~0ull;
   c->pass_hint = 0;         // passing windows of the last Bloom stage (sizes its partitions)
   c->kxg = 0;
+  c->agg_epoch = ~0ull;     // sharded protocol: the pre-aggregation verdict and its split
 }
 
 int set_reads_common(p3_ctx* c, u64 n_reads, u64 n_bases, u32 min_len) {

@@ -633,23 +633,33 @@ int agg_local(p3_ctx* c) {
   if ((rc = ensure(c, c->tpos, (((size_t)P3_NB << 5) << ts_log2) * 8))) return rc;
   if ((rc = ensure(c, c->sb_info, ((size_t)P3_NB << 5) * 16))) return rc;
   u64 h[6];
-  HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-  LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
-             (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
-             sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
-             (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
-  HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
-  const u64 records = h[5];  // this rank's windows (left by the partition step)
-  c->agg_distinct_est = distinct_est;
-  // Break-even, from the one-GPU emulation of 8 ranks (tools/exp_loopback_scale.py 8 1000000 {1,2}): at 2.56
-  // records per distinct key the aggregation costs this rank 1.2 ms of kernels more per pass and takes 634 MB off
-  // what it sends.  A GPU cannot push more than 7 links x ~76 GB/s = 0.54 TB/s out (all-to-all in practice: about
-  // 0.3), i.e. those bytes cost 1.2-2.1 ms on the links: worth it from about 2 records per key, not below.
-  if (h[3] || (c->agg_opt != 2 && records < 2 * distinct_est)) return P3_OK;
   u32 sbits = 1;
-  while (sbits < 5 && distinct_est / ((u64)P3_NB << sbits) > 11000) sbits++;
+  if (c->agg_epoch == c->reads_epoch && c->agg_opt_seen == c->agg_opt) {
+    // the same reads as in the last pass: its verdict and split stand (no sample launch, no synchronisation for it)
+    if (!c->agg_verdict) return P3_OK;
+    sbits = c->agg_sbits;
+  } else {
+    HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+    LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
+               (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
+               sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
+               (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+    HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
+    const u64 records = h[5];  // this rank's windows (left by the partition step)
+    c->agg_distinct_est = distinct_est;
+    c->agg_epoch = c->reads_epoch;
+    c->agg_opt_seen = c->agg_opt;
+    c->agg_verdict = false;
+    // Break-even, from the one-GPU emulation of 8 ranks (tools/exp_loopback_scale.py 8 1000000 {1,2}): at 2.56
+    // records per distinct key the aggregation costs this rank 1.2 ms of kernels more per pass and takes 634 MB off
+    // what it sends.  A GPU cannot push more than 7 links x ~76 GB/s = 0.54 TB/s out (all-to-all in practice: about
+    // 0.3), i.e. those bytes cost 1.2-2.1 ms on the links: worth it from about 2 records per key, not below.
+    if (h[3] || (c->agg_opt != 2 && records < 2 * distinct_est)) return P3_OK;
+    c->agg_verdict = true;
+    while (sbits < 5 && distinct_est / ((u64)P3_NB << sbits) > 11000) sbits++;
+  }
   for (;; sbits++) {
     if (sbits > 5) return P3_OK;
     const u32 nsb = P3_NB << sbits;
@@ -662,6 +672,7 @@ int agg_local(p3_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!h[3]) break;
   }
+  c->agg_sbits = sbits;  // (what worked: the next pass over these reads starts there)
   HIPCHK(c, hipMemsetAsync(st + 28, 0, 3 * 8, c->stream));
   LAUNCH(c, "k_agg_hist", k_agg_hist, P3_NB * P3_NWG / 256, 256, (const uint4*)c->sb_info.p, sbits, (u32*)c->ghist.p);
   if ((rc = do_scan(c, st + 28))) return rc;

@@ -108,6 +108,10 @@ struct p3_ctx {
   bool agg = false;          // this rank's send partition is pre-aggregated (apart)
   DevBuf apart;
   u64 agg_padded = 0, agg_distinct_est = 0;
+  u64 agg_epoch = ~0ull;  // reads_epoch of the cached pre-aggregation verdict (agg_verdict, agg_sbits; agg_opt_seen = the option then)
+  bool agg_verdict = false;
+  u32 agg_sbits = 1;
+  int agg_opt_seen = -1;
   // oversized single-GPU inputs: the position space is cut into `chunks` (2, 4 or 8) ranges of <= 2^30 positions that
   // the count stage treats as sources; gate and Bloom stages then run chunk by chunk
   u32 chunks = 1;  // 2, 4, 8 or 16 when in use
