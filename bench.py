@@ -310,6 +310,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, 31 if config == 5 else ks[0], 2)
         print(json.dumps(out))
+    if pipe is not None:
+        pipe.close()  # (communicators of the in-library exchange first, then the contexts)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

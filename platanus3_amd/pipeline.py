@@ -309,7 +309,11 @@ class Pipeline:
         return self.comm.all_reduce_sum(self.ctx.count_stats()["n_distinct"])
 
     def count_stats(self):
-        return self.ctx.count_stats()
+        st = dict(self.ctx.count_stats())
+        if self.world > 1:  # the table is sharded by bucket owner: totals are sums over the ranks (collective)
+            st["n_solid"] = self.comm.all_reduce_sum(st["n_solid"])
+            st["n_distinct"] = self.comm.all_reduce_sum(st["n_distinct"])
+        return st
 
     def passing_kmers(self):
         return self.comm.all_reduce_sum(self.ctx.bloom_stats()["n_passing"])
@@ -551,7 +555,7 @@ class VirtualRanks:
         return self._each(lambda p: p.passing_kmers())[0]
 
     def count_stats(self):
-        return {"n_solid": self._each(lambda p: p.comm.all_reduce_sum(p.ctx.count_stats()["n_solid"]))[0]}
+        return self._each(lambda p: p.count_stats())[0]
 
     def parallelism(self):
         return "reads sharded by index x%d%s (%d protocol ranks per GPU%s)" % (
