@@ -509,26 +509,46 @@ static int group_reads_by_key(p3_ctx* c, u32 W, DevBuf& grouped, std::vector<u32
                               u64* off_reads, u64* off_bases) {
   int rc;
   const u64 n = c->n_reads;
-  DevBuf d_owner, d_len, d_pos;
+  DevBuf d_owner, d_len, d_pos;  // (d_owner holds the 64-bit shard keys)
   auto done = [&](int code) {
     release(d_owner);
     release(d_len);
     release(d_pos);
     return code;
   };
-  if ((rc = ensure(c, d_owner, (n + 1) * 4)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
+  if ((rc = ensure(c, d_owner, (n + 1) * 8)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
       (rc = ensure(c, grouped, c->n_bases + 64)))
     return done(rc);
   if (n) {
-    hipLaunchKernelGGL(k_shard_keys, dim3(grid_for(n, 256, 1u << 30)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n, W,
-                       (u32*)d_owner.p, (u32*)d_len.p);
+    hipLaunchKernelGGL(k_shard_keys, dim3(grid_for(n, 256, 1u << 30)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
+                       (u64*)d_owner.p, (u32*)d_len.p);
     if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "k_shard_keys launch"));
   }
+  std::vector<u64> key(n);
   std::vector<u32> owner(n), len(n);
-  if (n && (hipMemcpyAsync(owner.data(), d_owner.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+  if (n && (hipMemcpyAsync(key.data(), d_owner.p, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(len.data(), d_len.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
     return done(fail(c, P3_EHIP, "shard keys copy"));
   if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, P3_EHIP, "shard keys sync"));
+  {
+    // keys shared by an outsized number of reads (a repeat whose 21-mer happens to hash low): their reads have no
+    // neighbourhood to keep together and would overload one group -- dealt round robin, like the reads without a 21-mer
+    std::vector<u64> sorted(key);
+    std::sort(sorted.begin(), sorted.end());
+    const u64 heavy = std::max<u64>(256, n / ((u64)W * 64));
+    std::vector<u64> heavy_keys;
+    for (u64 i = 0; i < n;) {
+      u64 j = i;
+      while (j < n && sorted[j] == sorted[i]) j++;
+      if (j - i > heavy && sorted[i] != ~0ULL) heavy_keys.push_back(sorted[i]);
+      i = j;
+    }
+    u64 rr = 0;
+    for (u64 i = 0; i < n; i++) {
+      const bool spread = key[i] == ~0ULL || (!heavy_keys.empty() && std::binary_search(heavy_keys.begin(), heavy_keys.end(), key[i]));
+      owner[i] = spread ? (u32)(rr++ % W) : (u32)(key[i] % W);
+    }
+  }
   for (u32 d = 0; d < W; d++) cnt_reads[d] = cnt_bases[d] = 0;
   for (u64 i = 0; i < n; i++) {
     cnt_reads[owner[i]]++;

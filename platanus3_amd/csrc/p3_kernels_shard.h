@@ -9,13 +9,15 @@
 // 164 -> 98 ms per pass.
 //
 //   k_shard_keys   one thread per read: rolling canonical 21-mer over the ASCII bases (unknown characters as in
-//                  src/BitCalc.cpp: 00 on both strands), 64-bit mix, minimum -> owner rank and read length
+//                  src/BitCalc.cpp: 00 on both strands), 64-bit mix, minimum -> shard key and read length.  The host maps
+//                  key -> group (key mod N), except for keys shared by an outsized number of reads (a repeat whose
+//                  21-mer happens to hash low would put all its reads on one rank): those reads are dealt round robin
 //   k_move_reads   one wave per read: bases copied to the read's place in the send buffer (reads grouped by owner)
 #pragma once
 #include "p3_device.h"
 
 static __global__ void __launch_bounds__(256) k_shard_keys(const uint8_t* __restrict__ bases, const u64* __restrict__ offsets,
-                                                    u64 n_reads, u32 n_ranks, u32* __restrict__ owner, u32* __restrict__ len) {
+                                                    u64 n_reads, u64* __restrict__ key, u32* __restrict__ len) {
   const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_reads) return;
   const u64 off0 = offsets[0];
@@ -32,7 +34,7 @@ static __global__ void __launch_bounds__(256) k_shard_keys(const uint8_t* __rest
       best = h < best ? h : best;
     }
   }
-  owner[r] = L >= 21 ? (u32)(best % n_ranks) : (u32)(r % n_ranks);  // (reads too short for a 21-mer: dealt round robin)
+  key[r] = L >= 21 ? best : ~0ULL;  // (~0: no 21-mer in this read -- the host deals those out round robin)
   len[r] = (u32)L;
 }
 

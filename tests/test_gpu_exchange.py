@@ -325,6 +325,48 @@ def test_resharded_reads_give_the_same_results(oracle, procs, v, k):
     assert min(sizes) > 0.5 * sum(sizes) / V  # and the deal is even enough
 
 
+def test_reshard_spreads_the_reads_of_a_heavy_key(oracle):
+    """a third of the reads are copies of ONE read (a repeat: one shard key for all of them): they are dealt round robin
+    instead of overloading one rank; results as ever equal the oracle's"""
+    V, k = 4, 31
+    b0, o0 = synth.reads(seed=66, total_reads=9000, read_len=150)
+    reads = [b0[int(o0[i]):int(o0[i + 1])].tobytes() for i in range(9000)]
+    reads = reads[:6000] + [reads[7]] * 3000
+    order = np.random.RandomState(3).permutation(len(reads))
+    reads = [reads[i] for i in order]
+    b = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    o = (np.arange(len(reads) + 1, dtype=np.uint64) * 150)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    g = capi.Group(V, None)
+    per = len(reads) // V
+    results, sizes, errors = [None] * V, [None] * V, []
+
+    def worker(i):
+        try:
+            comm = capi.Comm.member(g, i)
+            ctx = capi.Context(0)
+            ctx.load_reads(b[int(o[i * per]):int(o[(i + 1) * per])], o[i * per:(i + 1) * per + 1] - o[i * per], min_len=k)
+            ctx.mr_reshard_reads(comm)
+            ctx.mr_run_pass(comm, k, m, H)
+            keys, counts = ctx.export_counts()
+            results[i] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            sizes[i] = ctx.count_stats()["n_windows"]
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(V)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    g.close()
+    assert not errors, errors
+    _check_union(oracle, b, o, k, m, H, results)
+    assert max(sizes) < 1.15 * sum(sizes) / V, sizes   # (a third of the reads on one rank would be 1.75 x the mean)
+
+
 def test_group_member_failure_does_not_hang():
     """a member that fails (no reads loaded) aborts the group: the other member returns an error instead of waiting"""
     g = capi.Group(2, None)
