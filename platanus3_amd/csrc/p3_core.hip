@@ -18,13 +18,6 @@ int fail(p3_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
-#define HIPCHK(c, expr)                                                                              \
-  do {                                                                                               \
-    hipError_t e_ = (expr);                                                                          \
-    if (e_ != hipSuccess) return fail((c), P3_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                                      __FILE__, __LINE__);                                           \
-  } while (0)
-
 void release(DevBuf& b);
 
 void free_outgrown(p3_ctx* c) {
