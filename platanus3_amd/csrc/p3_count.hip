@@ -445,8 +445,11 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
   HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
   // records per (cell, workgroup) segment of one group: (records / groups) / (1024 cells x 256 workgroups)
-  const double total = (mr || chunked) ? (double)c->rx_records * 1.02
-                                       : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
+  // (multi-rank: a workgroup splits the data of ONE source, and the sources' blobs differ in size -- one rank may send
+  // pre-aggregated records, its neighbour raw ones, 2.5x as many -- so the segments are sized by the LARGEST blob)
+  const double total = mr ? (double)std::max<u64>(c->rx_src_max * n_src, c->rx_records) * 1.02
+                          : chunked ? (double)c->rx_records * 1.02
+                                    : (c->host_windows ? (double)c->host_windows * 1.02 : (double)c->n_words * 32);
   const u32 segcap = segcap_for(c, total / ((double)groups * P3_NB * P3_NWG));
   // once an estimate has overflowed for these reads (level >= 1), every cell gets its own capacity from a sample of
   // the group's input (a heavy key fills ONE cell): a quarter more room than the uniform layout, shared by need
@@ -497,9 +500,13 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (h[26] || h[27]) {
+    const bool var_was = var_caps_on(c);
+    const u32 level_was = c->ad.est_boost;
     est_overflowed(c);
-    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded (second-level partition of the count stage: segment %llu, sampled layout %llu; per-cell capacities %s)",
-                (unsigned long long)h[26], (unsigned long long)h[27], var_caps_on(c) ? "on" : "off");
+    return fail(c, P3_ERETRY_INTERNAL, "estimated segment capacity exceeded (second-level partition of the count stage: segment %llu, "
+                "sampled layout %llu; per-cell capacities %s, level %u; %llu records from %u sources, largest %llu, %u groups, %u records per segment, split %u+%u)",
+                (unsigned long long)h[26], (unsigned long long)h[27], var_was ? "on" : "off", level_was, (unsigned long long)c->rx_records,
+                n_src, (unsigned long long)c->rx_src_max, groups, segcap, xg, sbits);
   }
   if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
     c->ad.distinct_cap = maxd * 2;

@@ -100,6 +100,7 @@ struct p3_ctx {
   DevBuf rx_roff, rx_part_buf, rx_ghist_buf, rx_segoff_buf, or_tmp;
   void *rx_part = nullptr, *rx_ghist = nullptr, *rx_segoff = nullptr;
   u64 rx_records = 0;
+  u64 rx_src_max = 0;  // multi-rank: records of the largest received blob (sources need not agree on pre-aggregation)
   bool mr_partitioned = false;
   bool protocol = false;  // p3_mr_config was called: blobs must be contiguous, so segment offsets stay exact
   bool reparted = false;  // the received records have been split into 1024 local cells (n_ranks > 1)

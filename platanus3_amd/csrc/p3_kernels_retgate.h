@@ -269,33 +269,38 @@ static __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ 
 // ---- sender-side pre-aggregation (multi-rank): k_part_count in P3_K2_AGG_OUT mode leaves one record per distinct
 // local key in its sub-bucket's window of the pair buffer; these two kernels turn that into a partition in the
 // standard format (256 segments per bucket).
-// A sub-bucket's n records are laid out over per = 256 >> sbits consecutive segments in slices of
-// ceil(n / per) rounded up to 16 records (so only the last slice is padded): downstream kernels that share work by
-// segment index (k_split, k_repart_*) then see a balanced partition, as from the level-1 scatter.
-__device__ __forceinline__ u32 agg_slice(u32 n, u32 per) { return (((n + per - 1) / per) + 15u) & ~15u; }
+// The records of a bucket's 2^sbits sub-bucket tables are DEALT over the 256 segments -- record t of a table goes to
+// segment t mod 256 -- so that every segment holds its share of every sub-bucket.  (Laying a table out over its own
+// 256 >> sbits consecutive segments, as this did at first, makes a segment single-sub-bucket: the owner's k_split, whose
+// workgroups read a few segments per bucket and split by the very bits that select the sub-bucket, then sends a
+// workgroup's records to a quarter of its cells at a 16-way sender split -- four times the estimated segment fill, found
+// at 6.25 M reads per rank.)  Inside a segment the tables' shares follow each other in table order.
+__device__ __forceinline__ u32 agg_share(u32 n, u32 j) { return n / P3_NWG + (j < n % P3_NWG ? 1u : 0u); }  // records t < n with t mod 256 == j
 
 static __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P3_NB * P3_NWG) return;
   const u32 pb = i / P3_NWG, j = i % P3_NWG;
-  const u32 per = P3_NWG >> sbits, sub = j / per, sl = j % per;
-  const u32 n = sb_info[(pb << sbits) + sub].y;
-  const u32 slice = agg_slice(n, per);
-  const u32 done = sl * slice;
-  ghist[i] = done >= n ? 0u : (n - done < slice ? n - done : slice);
+  u32 total = 0;
+  for (u32 s = 0; s < (1u << sbits); s++) total += agg_share(sb_info[(pb << sbits) + s].y, j);
+  ghist[i] = total;
 }
 
 static __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
                                                      const u32* __restrict__ seg_off, u32 sbits, u32 ts_log2,
                                                      u64* __restrict__ out) {
+  __shared__ u32 first[P3_NWG];  // where this table's share starts inside segment j
   const u32 sb = blockIdx.x;
   const u32 pb = sb >> sbits, sub = sb & ((1u << sbits) - 1);
   const u32 n = sb_info[sb].y;
-  const u32 per = P3_NWG >> sbits;
-  const u32 slice = agg_slice(n, per);
+  for (u32 j = threadIdx.x; j < P3_NWG; j += blockDim.x) {
+    u32 before = 0;
+    for (u32 s = 0; s < sub; s++) before += agg_share(sb_info[(pb << sbits) + s].y, j);
+    first[j] = seg_off[pb * P3_NWG + j] + before;
+  }
+  __syncthreads();
   const u64* src = pairs + ((u64)sb << ts_log2);
-  const u32* so = seg_off + pb * P3_NWG + sub * per;
-  for (u32 t = threadIdx.x; t < n; t += blockDim.x) out[so[t / slice] + (t % slice)] = src[t];
+  for (u32 t = threadIdx.x; t < n; t += blockDim.x) out[first[t % P3_NWG] + t / P3_NWG] = src[t];
 }
 
 // ---- k_split: second-level partition of position records ----------------------------------------------------------

@@ -98,6 +98,8 @@ int p3_mr_count_recv_alloc(p3_ctx* c, const uint64_t* recv_records, void** d_rpa
   c->rx_ghist = c->rx_ghist_buf.p;
   c->rx_segoff = c->rx_segoff_buf.p;
   c->rx_records = roff[c->n_ranks];
+  c->rx_src_max = 0;  // the largest blob: its workgroups fill their split segments fastest (count_split sizes by it)
+  for (u32 s = 0; s < c->n_ranks; s++) c->rx_src_max = std::max<u64>(c->rx_src_max, recv_records[s]);
   c->reparted = false;
   c->rx_weighted = c->part_pos;  // any source may have pre-aggregated; raw records decode as weight 1
   *d_rpart = c->rx_part;
