@@ -681,14 +681,18 @@ int agg_local(p3_ctx* c) {
   }
   c->agg_sbits = sbits;  // (what worked: the next pass over these reads starts there)
   HIPCHK(c, hipMemsetAsync(st + 28, 0, 3 * 8, c->stream));
-  LAUNCH(c, "k_agg_hist", k_agg_hist, P3_NB * P3_NWG / 256, 256, (const uint4*)c->sb_info.p, sbits, (u32*)c->ghist.p);
+  // tables per block of segments: as blocked as the owners' reading pattern allows (p3_kernels_retgate.h); "agg_layout" = 1 + log2
+  AggLayout lay{sbits, 0};
+  while ((1u << (sbits - lay.m_log2)) > c->n_ranks && lay.m_log2 < sbits) lay.m_log2++;
+  if (c->agg_layout_opt) lay.m_log2 = std::min<u32>((u32)c->agg_layout_opt - 1, sbits);
+  LAUNCH(c, "k_agg_hist", k_agg_hist, P3_NB * P3_NWG / 256, 256, (const uint4*)c->sb_info.p, lay, (u32*)c->ghist.p);
   if ((rc = do_scan(c, st + 28))) return rc;
   u64 tot[3];
   HIPCHK(c, hipMemcpyAsync(tot, st + 28, sizeof tot, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((rc = ensure(c, c->apart, (tot[1] + 16) * 8))) return rc;
   LAUNCH(c, "k_agg_compact", k_agg_compact, P3_NB << sbits, 256, (const u64*)c->tpos.p, (const uint4*)c->sb_info.p,
-         (const u32*)c->seg_off.p, sbits, ts_log2, (u64*)c->apart.p);
+         (const u32*)c->seg_off.p, lay, ts_log2, (u64*)c->apart.p);
   c->agg = true;
   c->agg_padded = tot[1];
   return P3_OK;

@@ -113,6 +113,7 @@ struct p3_ctx {
   bool agg_verdict = false;
   u32 agg_sbits = 1;
   int agg_opt_seen = -1;
+  int agg_layout_opt = 0;  // 0 = automatic, 1 + log2(sub-bucket tables per block of segments) otherwise (tests and measurements)
   // oversized single-GPU inputs: the position space is cut into `chunks` (2, 4 or 8) ranges of <= 2^30 positions that
   // the count stage treats as sources; gate and Bloom stages then run chunk by chunk
   u32 chunks = 1;  // 2, 4, 8 or 16 when in use

@@ -269,38 +269,51 @@ static __global__ void __launch_bounds__(256) k_sum_u32(const u32* __restrict__ 
 // ---- sender-side pre-aggregation (multi-rank): k_part_count in P3_K2_AGG_OUT mode leaves one record per distinct
 // local key in its sub-bucket's window of the pair buffer; these two kernels turn that into a partition in the
 // standard format (256 segments per bucket).
-// The records of a bucket's 2^sbits sub-bucket tables are DEALT over the 256 segments -- record t of a table goes to
-// segment t mod 256 -- so that every segment holds its share of every sub-bucket.  (Laying a table out over its own
-// 256 >> sbits consecutive segments, as this did at first, makes a segment single-sub-bucket: the owner's k_split, whose
-// workgroups read a few segments per bucket and split by the very bits that select the sub-bucket, then sends a
-// workgroup's records to a quarter of its cells at a 16-way sender split -- four times the estimated segment fill, found
-// at 6.25 M reads per rank.)  Inside a segment the tables' shares follow each other in table order.
-__device__ __forceinline__ u32 agg_share(u32 n, u32 j) { return n / P3_NWG + (j < n % P3_NWG ? 1u : 0u); }  // records t < n with t mod 256 == j
+// A bucket's 2^sbits sub-bucket tables are laid out in BLOCKS of consecutive segments: m = tables per block, a block =
+// 256 m >> sbits segments, and the records of a block's tables are dealt over its segments in chunks of 16 (128 bytes:
+// reads and writes stay coalesced; chunk c of a table -> segment c mod block size).  m = 1 keeps a segment to ONE
+// sub-bucket: the owner's k_split then sends a lane group's records to few cells and runs five times faster than on mixed
+// segments (0.41 vs 2.06 ms for 64 M records, 8 ranks).  But an owner workgroup reads only n_ranks segments per bucket,
+// 256 / n_ranks apart, and splits by the very bits that select the sub-bucket: with more tables than ranks and m = 1 it
+// would meet only some of them and fill those cells several times over (found at 6.25 M reads per rank: a 16-way sender
+// split against 4 ranks overflowed every estimate and fell back to exact offsets, 425 instead of 190 ms per pass).  So
+// m = max(1, tables / n_ranks): as blocked as the owners' reading pattern allows.
+struct AggLayout {
+  u32 sbits, m_log2;  // tables per bucket = 1 << sbits, tables per block = 1 << m_log2
+};
+__device__ __forceinline__ u32 agg_block_segs(const AggLayout& a) { return (P3_NWG << a.m_log2) >> a.sbits; }
+// records t < n of a table that land in segment number q of its block: (t / 16) mod bs == q
+__device__ __forceinline__ u32 agg_share(u32 n, u32 q, u32 bs) {
+  const u32 round = 16u * bs, rem = n % round;
+  return (n / round) * 16u + (q < rem / 16u ? 16u : (q == rem / 16u ? rem % 16u : 0u));
+}
 
-static __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, u32 sbits, u32* __restrict__ ghist) {
+static __global__ void __launch_bounds__(256) k_agg_hist(const uint4* __restrict__ sb_info, AggLayout a, u32* __restrict__ ghist) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P3_NB * P3_NWG) return;
   const u32 pb = i / P3_NWG, j = i % P3_NWG;
+  const u32 bs = agg_block_segs(a), blk = j / bs, q = j % bs, m = 1u << a.m_log2;
   u32 total = 0;
-  for (u32 s = 0; s < (1u << sbits); s++) total += agg_share(sb_info[(pb << sbits) + s].y, j);
+  for (u32 s = 0; s < m; s++) total += agg_share(sb_info[(pb << a.sbits) + blk * m + s].y, q, bs);
   ghist[i] = total;
 }
 
 static __global__ void __launch_bounds__(256) k_agg_compact(const u64* __restrict__ pairs, const uint4* __restrict__ sb_info,
-                                                     const u32* __restrict__ seg_off, u32 sbits, u32 ts_log2,
+                                                     const u32* __restrict__ seg_off, AggLayout a, u32 ts_log2,
                                                      u64* __restrict__ out) {
-  __shared__ u32 first[P3_NWG];  // where this table's share starts inside segment j
+  __shared__ u32 first[P3_NWG];  // where this table's share starts inside segment q of its block
   const u32 sb = blockIdx.x;
-  const u32 pb = sb >> sbits, sub = sb & ((1u << sbits) - 1);
+  const u32 pb = sb >> a.sbits, sub = sb & ((1u << a.sbits) - 1);
   const u32 n = sb_info[sb].y;
-  for (u32 j = threadIdx.x; j < P3_NWG; j += blockDim.x) {
+  const u32 bs = agg_block_segs(a), m = 1u << a.m_log2, blk = sub / m, within = sub % m;
+  for (u32 q = threadIdx.x; q < bs; q += blockDim.x) {
     u32 before = 0;
-    for (u32 s = 0; s < sub; s++) before += agg_share(sb_info[(pb << sbits) + s].y, j);
-    first[j] = seg_off[pb * P3_NWG + j] + before;
+    for (u32 s = 0; s < within; s++) before += agg_share(sb_info[(pb << a.sbits) + blk * m + s].y, q, bs);
+    first[q] = seg_off[pb * P3_NWG + blk * bs + q] + before;
   }
   __syncthreads();
   const u64* src = pairs + ((u64)sb << ts_log2);
-  for (u32 t = threadIdx.x; t < n; t += blockDim.x) out[first[t % P3_NWG] + t / P3_NWG] = src[t];
+  for (u32 t = threadIdx.x; t < n; t += blockDim.x) out[first[(t >> 4) % bs] + (t / (16u * bs)) * 16u + (t & 15u)] = src[t];
 }
 
 // ---- k_split: second-level partition of position records ----------------------------------------------------------

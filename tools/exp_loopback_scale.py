@@ -46,6 +46,8 @@ def _worker(r):
     b, o = shards[r] if shards is not None else synth.reads(seed=2, total_reads=total, first_read=r * per, n_reads=per, read_len=150)
     pipe = Pipeline(device=0, rank=r, world=world, comm=lw.comm(r))
     pipe.ctx.set_option('mr_aggregate', agg)
+    if os.environ.get("AGG_LAYOUT"):
+        pipe.ctx.set_option('agg_layout', int(os.environ["AGG_LAYOUT"]))
     pipe.load_reads(b, o, min_len=k)
     pipe.run_pass(k, m, H)
     if r == 0:
