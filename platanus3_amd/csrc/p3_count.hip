@@ -667,16 +667,54 @@ int agg_local(p3_ctx* c) {
     c->agg_verdict = true;
     while (sbits < 5 && distinct_est / ((u64)P3_NB << sbits) > 11000) sbits++;
   }
+  // Plain form: 2^sbits workgroups per bucket, each reading the whole bucket.  From an 8-way split on (shards of a few
+  // million reads) that is mostly rejecting -- 4 M reads per rank: 16 readers, 10 of the rank's 31 ms -- so the local
+  // partition is split once more by those same sbits bits (k_split, groups of 1024 >> sbits buckets -> 1024 cells) and
+  // every cell is counted ONCE; the cell index is the sub-bucket index, so the outputs land where the plain form puts them.
+  if (c->split_opt >= 2 && sbits < (u32)c->split_opt - 1) sbits = (u32)c->split_opt - 1;  // (tests: the split form on small inputs)
   for (;; sbits++) {
     if (sbits > 5) return P3_OK;
     const u32 nsb = P3_NB << sbits;
     HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
-    LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
-               (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
-               (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
-               (u32)P3_K2_AGG_OUT);
-    HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    bool split_done = false;
+    if ((sbits >= 3 || c->split_opt >= 2) && c->split_opt != 1 && c->ad.est_ok && c->sizing_opt != 1) {
+      const u32 groups = 1u << sbits, rows = P3_NB >> sbits;
+      const u64 records = c->host_windows ? c->host_windows : c->n_words * 32;
+      const u32 segcap = segcap_for(c, (double)records * 1.02 / ((double)groups * P3_NB * P3_NWG));
+      if ((rc = ensure(c, c->lpart, (u64)P3_NB * P3_NWG * segcap * 8))) return rc;
+      if ((rc = ensure(c, c->seg_off2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+      if ((rc = ensure(c, c->ghist2, (size_t)P3_NB * P3_NWG * 4))) return rc;
+      HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
+      LAUNCH(c, "k_fixed_segoff", k_fixed_segoff, P3_NB * P3_NWG / 256, 256, (u32*)c->seg_off2.p, segcap);
+      const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
+      for (u32 g = 0; g < groups; g++) {
+        LAUNCH_LDS(c, "k_split", (k_split<u64, 0>), P3_NWG, P3_PART_THREADS, lds_split, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
+                   (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, g * rows, rows, sbits, (u64*)c->lpart.p,
+                   (EstSeg{segcap, (u32*)c->ghist2.p, st + 26, nullptr}), (const u32*)nullptr);
+        LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), P3_NB, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
+                   (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, 1u, rows, g * rows, sbits, 0u, ts_log2, (u64*)nullptr,
+                   (u32*)nullptr, (uint4*)c->sb_info.p + (size_t)g * P3_NB, st, (u64*)c->tpos.p + (((size_t)g * P3_NB) << ts_log2),
+                   (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+      }
+      u64 h2[P3_NSTAT];
+      HIPCHK(c, hipMemcpyAsync(h2, st, sizeof h2, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      if (h2[26]) {  // a split segment was full (skewed keys): the plain form below needs no estimate
+        HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
+      } else {
+        h[3] = h2[3];
+        split_done = true;
+      }
+    }
+    if (!split_done) {
+      LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
+                 (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
+                 (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
+                 (u32)P3_K2_AGG_OUT);
+      HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (!h[3]) break;
   }
   c->agg_sbits = sbits;  // (what worked: the next pass over these reads starts there)

@@ -513,7 +513,7 @@ static __global__ void __launch_bounds__(1024) k_part_count(const typename std::
         const u32 slot = (u32)(pr >> 32) & (TS - 1);
         const u32 cnt = tcnt[slot];
         const u32 hi = cnt == 1 ? ((u32)pr & 0x7fffffffu) : (0x80000000u | (cnt < 0x7fffffffu ? cnt : 0x7fffffffu));
-        tpairs[tbase + t] = ((u64)hi << 32) | ((u64)subsel << rem_bits) | tkey[slot];
+        tpairs[tbase + t] = ((u64)hi << 32) | (xbits ? ((u64)xval << (32 - xbits)) : 0ULL) | ((u64)subsel << rem_bits) | tkey[slot];
       }
       if (threadIdx.x == 0) sb_info[sb] = make_uint4(0u, nd, 0u, 0u);
       return;

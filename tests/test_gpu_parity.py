@@ -333,7 +333,7 @@ def test_config2_full_size_against_reference_checksums(ctx):
 
 
 @pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3),
-                                              (4, 31, 2, 10), (2, 29, 2, 11), (4, 31, 2, 20), (2, 33, 2, 21), (8, 31, 2, 20)])
+                                              (4, 31, 2, 10), (2, 29, 2, 11), (4, 31, 2, 20), (2, 33, 2, 21), (8, 31, 2, 20), (4, 31, 2, 21), (8, 27, 2, 21)])
 def test_multirank_loopback(oracle, world, k, gate, agg):
     """The REAL multi-rank protocol (HIP kernels, n_ranks = 2/4/8) on one GPU: `world` contexts driven by threads,
     exchanging through tests/loopback_comm.py.  Union of the shards == single-rank oracle on all reads.
