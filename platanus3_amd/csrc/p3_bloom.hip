@@ -310,13 +310,24 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       // several sweeps over the distinct keys (estimated-capacity form only), each keeping the probes of its slices
       u32 slice_log2 = 10;
       while (slice_log2 < 20 && ((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
+      // beyond 2^30 bits: buckets of two or four LDS slices (k_bloom_slices reads a bucket once per part) -- every sweep
+      // of the probe partition hashes all keys again, reading 4-byte positions twice or four times costs far less
+      // (as few sweeps as the 2^31 positions of one partition allow: a sweep's positions must fit 32-bit record indices)
+      const u64 n_pos = c->n_distinct_k * (u64)H;  // spec: last pass's count; the scatter checks the real one
+      auto sweeps_for = [&](u32 sub) { return (u32)((((m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub)) + P3_NB - 1) / P3_NB); };
+      auto fits = [&](u32 sub) {
+        const u32 sw = sweeps_for(sub);
+        return (sw == 1 || (est && sw <= 64)) && n_pos / sw + n_pos / 8 + 16ull * P3_NWG * P3_NB < (1ull << 31);
+      };
+      u32 sub_log2 = (u32)c->bloom_sub_opt;  // (tests force parts on small vectors)
+      while (sub_log2 < 2 && slice_log2 == 20 && sweeps_for(sub_log2) > 1 && fits(sub_log2 + 1)) sub_log2++;
+      slice_log2 += sub_log2;
       const u64 ns_total = (m + ((1ull << slice_log2) - 1)) >> slice_log2;
       const u32 sweeps = (u32)((ns_total + P3_NB - 1) / P3_NB);
-      const u64 n_pos = c->n_distinct_k * (u64)H;  // spec: last pass's count; the scatter checks the real one
       const bool sliced = c->bloom_slices_opt && (sweeps == 1 || (est && sweeps <= 64)) &&
                           n_pos / sweeps + n_pos / 8 + 16ull * P3_NWG * P3_NB < (1ull << 31);
       if (sliced) {
-        const size_t lds_bm = ((size_t)1 << (slice_log2 - 3)) + 64 + P3_VALID_CAP;
+        const size_t lds_bm = ((size_t)1 << (slice_log2 - sub_log2 - 3)) + 64 + P3_VALID_CAP;
         for (u32 sw = 0; sw < sweeps; sw++) {
           const u32 sbase = sw * P3_NB;
           const u32 ns = (u32)(ns_total - sbase < P3_NB ? ns_total - sbase : P3_NB);
@@ -347,9 +358,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                        (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
           }
           if (c->n_ranks > 1 || bwords_padded != bwords) HIPCHK(c, zero_bloom());  // (the slices cover words below bwords)
-          LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns, 1024, lds_bm, (const u32*)c->ppart.p,
+          LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns << sub_log2, 1024, lds_bm, (const u32*)c->ppart.p,
                      (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
-                     (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase);
+                     (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase, sub_log2);
         }
         c->bloom_mode = 3;
       } else {

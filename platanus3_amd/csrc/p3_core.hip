@@ -299,6 +299,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "mr_aggregate") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
     c->agg_opt = (int)value;
+  } else if (n == "bloom_sub") {
+    if (value < 0 || value > 2) return fail(c, P3_EBADARG, "bloom_sub must be 0, 1 or 2");
+    c->bloom_sub_opt = (int)value;
   } else if (n == "agg_layout") {
     if (value < 0 || value > 6) return fail(c, P3_EBADARG, "agg_layout must be 0 (automatic) or 1 + log2(tables per block), at most 6");
     c->agg_layout_opt = (int)value;

@@ -791,26 +791,31 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
 
 // one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else
 // writes it in this mode).  n_u32 = number of u32 words of the whole vector.
+// sub_log2 > 0: a partition bucket spans 2^sub_log2 LDS-sized slices (vectors beyond 2^30 bits: fewer sweeps of the
+// probe partition, each of which hashes every key again); 2^sub_log2 workgroups read the bucket, each keeping the
+// positions of its part (the 4-byte positions are cheap to read twice or four times; the hashes are not cheap to redo).
 static __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
                                                        u32* __restrict__ bloom, const u64* __restrict__ cap_flag,
-                                                       u32 accumulate, u32 slice_base) {
+                                                       u32 accumulate, u32 slice_base, u32 sub_log2) {
   if (*cap_flag) return;  // the probe partition did not fit: the host repeats the stage
   extern __shared__ __align__(16) u32 lds[];
-  const u32 words = 1u << (slice_log2 - 5);
+  const u32 part_log2 = slice_log2 - sub_log2;  // bits one workgroup builds
+  const u32 words = 1u << (part_log2 - 5);
   u32* bm = lds;
   u32* sc = lds + words;
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
   for (u32 i = threadIdx.x; i < words; i += blockDim.x) bm[i] = 0;
   __syncthreads();
-  const u32 s = blockIdx.x;
+  const u32 s = blockIdx.x >> sub_log2, mine = blockIdx.x & ((1u << sub_log2) - 1u);
+  const u32 pmask = (1u << part_log2) - 1u;
   bucket_for_each<u32>(part, seg_off, ghist, s, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
 #pragma unroll
     for (int i = 0; i < 16; i++)
-      if (act & (1u << i)) atomicOr(&bm[r[i] >> 5], 1u << (r[i] & 31));
+      if ((act & (1u << i)) && (r[i] >> part_log2) == mine) atomicOr(&bm[(r[i] & pmask) >> 5], 1u << (r[i] & 31));
   });
   __syncthreads();
-  const u64 w0 = (u64)(slice_base + s) * words;
+  const u64 w0 = ((((u64)(slice_base + s)) << sub_log2) | mine) * words;
   for (u32 i = threadIdx.x; i < words; i += blockDim.x)
     if (w0 + i < n_u32) bloom[w0 + i] = accumulate ? (bloom[w0 + i] | bm[i]) : bm[i];  // accumulate: later position chunks
 }

@@ -132,6 +132,21 @@ def test_grouped_reads_give_the_same_results(oracle, chunks, groups):
         c.close()
 
 
+@pytest.mark.parametrize("sub,m", [(1, 3000017), (2, 3000017), (2, 40000003), (1, 1 << 22)])
+def test_probe_buckets_of_several_lds_slices(oracle, sub, m):
+    """vectors beyond 2^30 bits put two or four LDS-sized slices into one bucket of the probe partition (fewer sweeps, each
+    of which hashes every key again); k_bloom_slices then builds a bucket in parts.  `bloom_sub` forces that on small vectors."""
+    b, o = synth.reads(seed=21, total_reads=20000, read_len=150)
+    c = capi.Context(0)
+    try:
+        c.set_option("bloom_sub", sub)
+        for k in (31, 45):
+            run_and_compare(c, oracle, (b, o), k, m, 7)
+            assert c.get_info("bloom_mode") == 3
+    finally:
+        c.close()
+
+
 def test_timings_and_byte_counters(ctx):
     """p3_last_timings / p3_last_traffic (per-phase device times and byte counters): the counters
     follow section 8d's accounting -- 2 L + 16 (L - 20) + 16 D / R + m / (8 R) bytes per read in total"""
