@@ -346,8 +346,12 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __r
   const u32 wps = P3_NWG / n_src;  // workgroups per source
   const u32 src = blockIdx.x / wps, j0 = blockIdx.x % wps;
   const u32 n_items = rows * n_src;  // <= 1024
+  // items in segment-major order (item = t * rows + r): lane group g then walks the segments of ROW g one after the
+  // other (there are as many lane groups as rows), so a row's 2^xbits cells are fed by one lane group at a time -- 4 records
+  // per cell and step, the stager's design point.  (Row-major order put all n_src lane groups of a row to work at once:
+  // 4 n_src records per cell and step against rows of 16, i.e. refusals and extra rounds from 8 sources on.)
   for (u32 i = threadIdx.x; i < n_items; i += blockDim.x) {
-    const u32 r = i / n_src, t = i % n_src;
+    const u32 t = i / rows, r = i % rows;
     const u64 d = ((u64)src * desc_rows + first_row + r) * P3_NWG + j0 + t * wps;
     item_off[i] = in_segoff[d];
     item_cnt[i] = in_ghist[d];
@@ -386,7 +390,7 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_split(const REC* __r
     for (int t = 0; t < N; t++) bkt[t] = 0;
     if (it < n_items) {
       const uint4* vecs = reinterpret_cast<const uint4*>(data + off);
-      const u32 rbase = (it / n_src) << xbits;
+      const u32 rbase = (it % rows) << xbits;
       uint4 q[2];
 #pragma unroll
       for (int h = 0; h < 2; h++) {
