@@ -299,6 +299,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "mr_aggregate") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "mr_aggregate must be 0, 1 or 2");
     c->agg_opt = (int)value;
+  } else if (n == "pos_limit_log2") {
+    if (value != 0 && value != 31 && value != 32) return fail(c, P3_EBADARG, "pos_limit_log2 must be 0, 31 or 32");
+    c->pos_limit_log2_opt = (int)value;
   } else if (n == "bloom_sub") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "bloom_sub must be 0, 1 or 2");
     c->bloom_sub_opt = (int)value;

@@ -137,6 +137,7 @@ struct p3_ctx {
   u32 kgroups = 0;            // info: collected groups probed in the last chunked Bloom stage
   bool kcollect_pass = true;  // this pass: cleared by the first chunk when the collection would not fit in memory
   int boost_opt = 0;         // tests: 1 = no boost levels (an overflowing estimate goes straight to exact offsets)
+  int pos_limit_log2_opt = 0;  // experiment: log2 of the positions one probe partition may hold (0 = 31)
   int bloom_sub_opt = 0;     // tests: log2 of the LDS slices per probe-partition bucket (0..2; automatic beyond 2^30 bits)
   int lend_opt = 1;          // 1 = always lend the count partitions to the k-mer stage; 0 = only when memory is short
   int kgroup_opt = 0;        // tests: at most this many chunks per collected group (0 = as many as fit in memory)
