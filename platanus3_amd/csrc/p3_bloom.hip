@@ -155,7 +155,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
     const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
                        16 * 192 * sizeof(REC);
-    u32 sbits = 0, kxg = 0;
+    u32 sbits = 0, kxg = 0, kxg_next = 0;  // (kxg_next: deepening of the split noted for later passes)
     // plain form: one workgroup per sub-bucket, each reading the whole bucket (2^sbits reads of every record);
     // split form (kxg > 0), for large inputs: the k-mer records are partitioned a second time (k_split) into
     // 1024 cells per group of 1024 >> kxg buckets and every cell is read once
@@ -240,6 +240,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         sbits = 0;
         kxg = 1;
         while (kxg < 10 && (c->dall_n >> kxg) / P3_NB > ((u64)4 << ts_log2)) kxg++;
+        if (c->kxg_all_epoch == c->reads_epoch && c->kxg_all_k == k && c->kxg_all > kxg) kxg = c->kxg_all;
       }
       if (c->ksplit_opt >= 2 && est) {  // tests: force the split form (it only exists with estimated capacities)
         kxg = (u32)c->ksplit_opt - 1;
@@ -266,6 +267,17 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if (kxg) kxg++;
         else sbits++;
       }
+      // The loop stops at the smallest split whose sets hold their keys -- sets up to 7/8 full, where a probe chain is
+      // several slots long.  The split REMEMBERED for the next chunk / pass over these reads aims at kmer_load_pct percent
+      // of the slots instead.  Measured (profiles/r02_kmer_split_load.txt): 50 M reads grouped by minimizer, split 3 -> 4,
+      // k_kmer_dedup 45.9 -> 33.8 ms per pass; 16 M reads 3 -> 4, 12.9 -> 11.3 ms; one level deeper still and the fixed
+      // cost of 2^split more launches (clearing and scanning 1024 sets, ~50 us) wins again.  The collected list of all
+      // chunks (kphase 2) stays at its smallest split: one launch series over few records, deepening it only cost.
+      if (use_dedup && kxg && c->kphase != 2 && !c->kpart_sk && !c->ksplit_opt) {
+        const u32 pct = c->kload_pct_opt ? (u32)c->kload_pct_opt : p3_ctx::KLOAD_PCT;
+        const u64 per_split = ((u64)P3_NB << ts_log2) * pct / 100;  // distinct keys one round's 1024 sets should hold
+        while (kxg_next < 8 && h[0] > (per_split << kxg_next)) kxg_next++;
+      }
     }
     if (use_dedup && c->kphase == 1 && !c->dall_cap) {
       // first chunk: the global deduplication needs the list, its partition, the second-level partition and the
@@ -290,7 +302,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (use_dedup && c->kphase == 1) {
       // position chunk: keep this chunk's distinct k-mers for the global deduplication instead of probing them now
       c->ksbits = sbits;
-      c->kxg = kxg;
+      c->kxg = std::max(kxg, kxg_next);
       c->ksbits_epoch = c->reads_epoch;
       c->ksbits_k = k;
       c->n_distinct_k = h[0];
@@ -301,9 +313,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     } else if (use_dedup) {
       if (c->kphase != 2) {
         c->ksbits = sbits;
-        c->kxg = kxg;
+        c->kxg = c->spec ? kxg : std::max(kxg, kxg_next);
         c->ksbits_epoch = c->reads_epoch;
         c->ksbits_k = k;
+      } else {
+        c->kxg_all = std::max(kxg, kxg_next);
+        c->kxg_all_epoch = c->reads_epoch;
+        c->kxg_all_k = k;
       }
       if (!c->spec) c->n_distinct_k = h[0];
       // slices of 2^slice_log2 bits (<= 2^20: 128 KiB of LDS), 1024 per sweep; a vector of more than 2^30 bits takes

@@ -139,6 +139,7 @@ void forget_learnt(p3_ctx* c, bool new_reads) {
   c->sbits_epoch = ~0ull;
   c->pass_hint = 0;         // passing windows of the last Bloom stage (sizes its partitions)
   c->kxg = 0;
+  c->kxg_all_epoch = ~0ull;
   c->agg_epoch = ~0ull;     // sharded protocol: the pre-aggregation verdict and its split
 }
 
@@ -286,6 +287,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "kmer_split") {
     if (value < 0 || value > 11) return fail(c, P3_EBADARG, "kmer_split must be in [0,11]");
     c->ksplit_opt = (int)value;
+  } else if (n == "kmer_load_pct") {
+    if (value < 0 || value > 100) return fail(c, P3_EBADARG, "kmer_load_pct must be in [0,100]");
+    c->kload_pct_opt = (int)value;
   } else if (n == "distinct_cap") {  // tests: entries of the estimate-sized count table outputs (position chunks)
     if (value < 0) return fail(c, P3_EBADARG, "distinct_cap must be >= 0");
     c->ad.distinct_cap = (u64)value;

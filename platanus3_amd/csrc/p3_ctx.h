@@ -129,6 +129,10 @@ struct p3_ctx {
   size_t arena_bytes = 0, arena_used = 0;
   u64 chunk_w0[17] = {0};
   int ksplit_opt = 0;         // 0 = auto, x+1 (2..11) = force x split bits for the k-mer records (tests)
+  static constexpr u32 KLOAD_PCT = 50;
+  int kload_pct_opt = 0;      // split form: distinct keys per set slot aimed at, in percent (0 = KLOAD_PCT, 100 = smallest split that fits)
+  u32 kxg_all = 0, kxg_all_k = 0;  // split bits learnt for the collected list of all chunks (kphase 2)
+  u64 kxg_all_epoch = ~0ull;
   u32 kxg = 0, hint_kxg = 0;  // split bits of the k-mer records' second-level partition (0 = not used)
   DevBuf klpart, zero8;
   // position chunks, Bloom stage: kphase 1 = a chunk's distinct k-mers are appended to `dall` instead of being

@@ -223,6 +223,12 @@ class Pipeline:
         """a sharded job: deal the reads out once more by genomic neighbourhood (p3_mr_reshard_reads: one all-to-all of the
         reads before the passes; no result depends on which rank holds a read, the work per rank does).  Returns whether
         it happened (the in-library exchange is needed)."""
+        if not self.protocol and self.world == 1 and self.ctx is not None:
+            # one GPU: the same one-off step without the exchange -- the reads in the order of their minimizer's group, so
+            # that a position chunk of a large input meets few distinct k-mers (p3_group_reads)
+            self.ctx.group_reads(0)
+            self.resharded = True
+            return True
         if self.native is None:
             return False
         self.ctx.mr_reshard_reads(self.native)

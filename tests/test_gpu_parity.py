@@ -771,6 +771,38 @@ def test_kmer_second_level_partition(oracle, split, k):
     c.close()
 
 
+@pytest.mark.parametrize("k,chunks", [(31, 0), (31, 4), (63, 0)])
+def test_kmer_split_learnt_load(oracle, k, chunks):
+    """The second-level partition of the k-mer records starts at the smallest split whose LDS sets hold their keys and
+    REMEMBERS a deeper one for the next chunk / pass (kmer_load_pct percent of a set's slots, default 50): small sets
+    (tsk_log2 = 7, 5) force the split form on a small input; a 5 % target must end deeper than the 100 % one, and every
+    pass -- the careful first, the replayed ones with the remembered split -- gives the reference's vector and seeds."""
+    b, o = synth.reads(seed=77, total_reads=60000, read_len=150)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    depth = {}
+    for pct in (100, 5):
+        c = capi.Context(0)
+        try:
+            c.set_option("tsk_log2", 5 if chunks else 7)   # (a chunk holds a quarter of the keys: smaller sets still)
+            c.set_option("kmer_load_pct", pct)
+            if chunks:
+                c.set_option("chunks", chunks)
+            c.load_reads(b, o, k)
+            for _ in range(3):
+                c.run_pass(k, m, H)
+                assert c.get_info("bloom_mode") == 3
+                assert np.array_equal(c.export_bloom(), ebloom)
+                c.k = k
+                assert seeds_as_strings(c) == eseeds
+            depth[pct] = c.get_info("ksplit_xbits")
+            assert depth[pct] > 0
+        finally:
+            c.close()
+    assert depth[5] > depth[100]
+
+
 @pytest.mark.parametrize("seed", range(32))
 def test_random_configurations(oracle, seed):
     """Randomised sweep over input shapes AND path options: every combination must equal the oracle, on the first
@@ -818,6 +850,8 @@ def test_random_configurations(oracle, seed):
             opts["bloom_slices"] = 0
         if rng.random() < 0.2:
             opts["est_boost"] = 0
+        if (seed + case) % 3 == 0:  # (not drawn from rng: the cases of the sweep stay the ones they were)
+            opts["kmer_load_pct"] = (5, 20, 100)[(seed * 7 + case) % 3]
         c = capi.Context(0)
         try:
             for name, v in opts.items():

@@ -31,7 +31,7 @@ for i in range(int(os.environ.get('P3_PASSES', '2'))):
           (i, c.timings()["ms_total"], dt * 1e3, nk / dt / 1e9, c.get_info("chunks"), c.get_info("split_xbits"), c.get_info("count_mode"), c.get_info("bloom_mode")), flush=True)
     import ctypes as _C
     c.L.p3_last_error.restype = _C.c_char_p
-    print("   est_fallbacks=%d est_level=%d ksplit_xbits=%d ksbits=%d kmer_groups=%d last_error=%r" % (c.get_info("est_fallbacks"), c.get_info("est_level"), c.get_info("ksplit_xbits"), c.get_info("ksbits"), c.get_info("kmer_groups"), c.L.p3_last_error(c.h)), flush=True)
+    print("   est_fallbacks=%d est_level=%d ksplit_xbits=%d ksbits=%d kmer_groups=%d distinct=%d last_error=%r" % (c.get_info("est_fallbacks"), c.get_info("est_level"), c.get_info("ksplit_xbits"), c.get_info("ksbits"), c.get_info("kmer_groups"), c.get_info("distinct_kmers"), c.L.p3_last_error(c.h)), flush=True)
 print(c.count_stats(), c.bloom_stats(), flush=True)
 assert c.count_stats()["n_windows"] == R * (L - 20)
 c.reset_kernel_stats(); c.set_profiling(True); c.run_pass(k, m, H); c.set_profiling(False)
