@@ -86,6 +86,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "kmer_split"  0 = auto: the same second-level partition for the passing k-mer records of the Bloom stage, taken from
  *                 an 8-way set split on; x+1 (2..11) = force x split bits (tests); "count_split" = 1 switches it off
  *                 as well.  p3_get_info "ksplit_xbits" reads back x.
+ *   "kmer_load_pct" the split REMEMBERED for the next position chunk / pass over the same reads leaves the k-mer sets
+ *                 this full, in percent of their slots (0 = default, 50; 100 = the smallest split whose sets hold their
+ *                 keys, which is what a first pass finds).  A speed knob only: results do not depend on it.
  *   "kmer_collect" position chunks, Bloom stage: 1 (default) = from four chunks on, the chunks' distinct passing k-mers
  *                 are collected (in groups of as many chunks as fit in device memory), deduplicated once more
  *                 (k_keys_scatter + the dedup machinery) and probed once per group instead of once per chunk;
