@@ -23,6 +23,7 @@ typedef unsigned __int128 u128;
 namespace {
 
 inline int nwords(int k) { return (2 * k + 63) / 64; }
+constexpr int MAXW = 96;  // words of the widest key: the reference's k = 3001 (src/Assemble.cpp:48) takes 94
 
 inline u128 mask_of(int k) { return (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
 
@@ -71,13 +72,13 @@ struct Roller {
   inline u128 canon() const { return fwd <= rc ? fwd : rc; }  // src/BitCalc.cpp:47-54 (tie -> fwd)
 };
 
-// The same for keys beyond two words (65 <= k <= 128; the reference's k = 101, src/Assemble.cpp:40): the key as an
+// The same for keys beyond two words (65 <= k <= 3001; the reference's k = 101 ... 3001, src/Assemble.cpp:40-49): the key as an
 // array of 64-bit words, word 0 least significant -- the layout of std::bitset<2k>.
 struct WideRoller {
   int k, nw;
-  uint64_t fwd[4], rc[4];
+  uint64_t fwd[MAXW], rc[MAXW];
   explicit WideRoller(int k_) : k(k_), nw(nwords(k_)) {
-    for (int t = 0; t < 4; t++) fwd[t] = rc[t] = 0;
+    for (int t = 0; t < MAXW; t++) fwd[t] = rc[t] = 0;
   }
   inline void push(char c) {
     // fwd = ((fwd << 2) | code) & mask
@@ -217,7 +218,7 @@ void p3o_encode_rc(const char* s, int k, uint64_t* key) {
 void p3o_complement(const uint64_t* key, int k, uint64_t* out) {
   // src/BitCalc.cpp:35-45: base i (from the LSB end) becomes base k-1-i, complemented (3-b).
   if (k > 64) {
-    uint64_t o[4] = {0, 0, 0, 0};
+    uint64_t o[MAXW] = {0};
     for (int i = 0; i < k; i++) {
       const uint64_t b = (key[(2 * i) >> 6] >> ((2 * i) & 63)) & 3;
       const int to = 2 * (k - 1 - i);
@@ -359,7 +360,7 @@ int p3o_make_bf(const char* bases, const uint64_t* offsets, uint64_t n_reads, ui
                 int k, uint64_t m, int H, uint64_t* bloom_words,
                 char* seed_chars, uint64_t seed_cap, uint64_t* n_seeds,
                 uint64_t* n_inserted, int* count_overflow) {
-  if (k < 21 || k > 128 || m == 0) return 2;
+  if (k < 21 || k > 3001 || m == 0) return 2;
   const uint64_t nw = (m + 63) / 64;
   std::memset(bloom_words, 0, nw * 8);
   std::set<std::string> seeds;
@@ -395,7 +396,7 @@ int p3o_make_bf(const char* bases, const uint64_t* offsets, uint64_t n_reads, ui
       if (i + 1 < (uint64_t)k) continue;
       const uint64_t idx = i + 1 - k;
       if (rmq[idx] >= 2) {
-        uint64_t kw[4] = {0, 0, 0, 0};
+        uint64_t kw[MAXW] = {0};
         if (wide) std::memcpy(kw, wk.canon(), 8 * wk.nw);
         else store_key(rk.canon(), k, kw);
         uint64_t h1, h2;
@@ -404,7 +405,7 @@ int p3o_make_bf(const char* bases, const uint64_t* offsets, uint64_t n_reads, ui
         for (int n = 0; n < H; n++) bloom_words[pos[n] >> 6] |= 1ULL << (pos[n] & 63);
         inserted++;
         if (!seeded) {
-          uint64_t fw[4] = {0, 0, 0, 0};
+          uint64_t fw[MAXW] = {0};
           if (wide) std::memcpy(fw, wk.fwd, 8 * wk.nw);
           else store_key(rk.fwd, k, fw);
           std::string sd(k, 'A');
@@ -433,7 +434,7 @@ void p3o_bloom_query(const uint64_t* bloom_words, uint64_t m, int H, const uint6
   const int nw = nwords(k);
   std::vector<uint64_t> pos(H > 0 ? H : 1);
   for (uint64_t i = 0; i < n; i++) {
-    uint64_t kw[4] = {0, 0, 0, 0};
+    uint64_t kw[MAXW] = {0};
     for (int t = 0; t < nw; t++) kw[t] = keys[i * nw + t];
     uint64_t h1, h2;
     double_hash(kw, k, &h1, &h2);

@@ -10,7 +10,7 @@
  * /root/reference by oracle/Makefile) and the fixtures it generated under tests/golden/
  * (tests/golden/make_golden.py).
  *
- * Keys: a k-mer of 2k bits (21 <= k <= 128) is `nw = (2k+63)/64` uint64 words, LOW word first
+ * Keys: a k-mer of 2k bits (21 <= k <= 3001) is `nw = (2k+63)/64` uint64 words, LOW word first
  * (= libstdc++ std::bitset word order); first base of the k-mer in the most significant used bits.
  */
 #ifndef P3_ORACLE_H

@@ -17,6 +17,9 @@ _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
+MAXW = 96  # words of the widest key (k = 3001 takes 94)
+
+
 def nwords(k):
     return (2 * k + 63) // 64
 
@@ -90,30 +93,30 @@ class Oracle:
     def encode_fwd(self, s, k=None):
         s = s.encode() if isinstance(s, str) else s
         k = k or len(s)
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(MAXW, np.uint64)
         self.lib.p3o_encode_fwd(s, k, out)
         return out[: nwords(k)].copy()
 
     def encode_rc(self, s, k=None):
         s = s.encode() if isinstance(s, str) else s
         k = k or len(s)
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(MAXW, np.uint64)
         self.lib.p3o_encode_rc(s, k, out)
         return out[: nwords(k)].copy()
 
     def _pad(self, key):
-        w = np.zeros(4, np.uint64)
+        w = np.zeros(MAXW, np.uint64)
         key = np.atleast_1d(np.asarray(key, dtype=np.uint64))
         w[: key.size] = key
         return w
 
     def complement(self, key, k):
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(MAXW, np.uint64)
         self.lib.p3o_complement(self._pad(key), k, out)
         return out[: nwords(k)].copy()
 
     def canonical(self, f, r, k):
-        out = np.zeros(4, np.uint64)
+        out = np.zeros(MAXW, np.uint64)
         self.lib.p3o_canonical(self._pad(f), self._pad(r), k, out)
         return out[: nwords(k)].copy()
 
@@ -327,7 +330,7 @@ class RefLib:
     def kat(self, seq, m, H):
         k = len(seq)
         nw = nwords(k)
-        f, r, c, cn = (np.zeros(4, np.uint64) for _ in range(4))
+        f, r, c, cn = (np.zeros(MAXW, np.uint64) for _ in range(4))
         sh = C.c_uint64()
         h12 = np.zeros(2, np.uint64)
         pos = np.zeros(max(H, 1), np.uint64)

@@ -560,19 +560,21 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
 }
 
 
-// Bloom stage for keys of three and four words (65 <= k <= 128, p3_kernels_wide.h): the gate as for the short keys,
-// then one direct insert per passing window and the per-read seeds.  No k-mer partition, no replay hints (every pass
-// takes the careful path), no seed set on the device (p3_export_seeds sorts on the host).
+// Bloom stage for keys of three and four words (65 <= k <= 128, p3_kernels_wide.h) and, NW = 0, of any width up to the
+// reference's k = 3001 (p3_kernels_long.h: the key's words are read from the packed streams): the gate as for the short
+// keys, then one direct insert per passing window and the per-read seeds.  No k-mer partition, no replay hints (every
+// pass takes the careful path), no seed set on the device (p3_export_seeds sorts on the host).
 template <int NW>
 int do_bloom_wide(p3_ctx* c, u32 k, u64 m, u32 H) {
   int rc;
+  const u32 nw_keys = NW ? (u32)NW : (u32)nw_of(k);
   const u64 nwa = c->n_words + P3_PAD_WORDS;
   const u64 bwords = (m + 63) / 64;
   const u64 bwords_padded = (bwords + c->n_ranks - 1) / c->n_ranks * c->n_ranks;
   if ((rc = ensure(c, c->S, nwa * 4))) return rc;
   if ((rc = ensure(c, c->P, nwa * 4))) return rc;
   if ((rc = ensure(c, c->bloom, bwords_padded * 8))) return rc;
-  if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * NW))) return rc;
+  if ((rc = ensure(c, c->seeds, (c->n_reads + 1) * 8 * nw_keys))) return rc;
   if ((rc = ensure(c, c->seed_valid, c->n_reads + 1))) return rc;
   u64* st = (u64*)c->dstats.p;
   // (position chunks: the count stage assembled S chunk by chunk over the whole stream)
@@ -593,11 +595,20 @@ int do_bloom_wide(p3_ctx* c, u32 k, u64 m, u32 H) {
   }
   HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
   const ModM mm = make_modm(m);
-  LAUNCH(c, "k_wide_bloom", (k_wide_bloom<NW>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
-         (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p, (u32*)c->P.p, st + 8);
-  HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-  LAUNCH(c, "k_wide_seeds", (k_wide_seeds<NW>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
-         (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  if constexpr (NW == 0) {
+    LAUNCH(c, "k_long_bloom", k_long_bloom, grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, nwa, k, mm, H, (u32*)c->bloom.p, (u32*)c->P.p, st + 8);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    LAUNCH(c, "k_long_seeds", k_long_seeds, grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
+           (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  } else {
+    constexpr int W = NW ? NW : 3;
+    LAUNCH(c, "k_wide_bloom", (k_wide_bloom<W>), grid_for(c->n_words), 256, (const u64*)c->fw.p, (const u64*)c->rcw.p,
+           (const u32*)c->endm.p, (const u32*)c->S.p, c->n_words, k, mm, H, (u32*)c->bloom.p, (u32*)c->P.p, st + 8);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    LAUNCH(c, "k_wide_seeds", (k_wide_seeds<W>), grid_for(c->n_reads, 256, 1024), 256, c->d_offsets, c->n_reads, c->min_len, k,
+           (const u32*)c->P.p, (const u64*)c->fw.p, (u64*)c->seeds.p, (uint8_t*)c->seed_valid.p, st + 10);
+  }
   c->seedset_ready = false;
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 h[3] = {0, 0, 0}, count_flag = 0;
@@ -645,6 +656,7 @@ int p3_make_bloom(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
   auto bloom_once = [&]() {
     if (nw_of(k) == 3) return do_bloom_wide<3>(c, k, m_bits, H);
     if (nw_of(k) == 4) return do_bloom_wide<4>(c, k, m_bits, H);
+    if (nw_of(k) > 4) return do_bloom_wide<0>(c, k, m_bits, H);
     if (c->chunks > 1) return nw_of(k) == 1 ? bloom_chunked<1>(c, k, m_bits, H) : bloom_chunked<2>(c, k, m_bits, H);
     return nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
   };
@@ -718,22 +730,22 @@ int p3_export_seeds(p3_ctx* c, uint64_t* fwd_keys, uint64_t cap, uint64_t* n) {
   }
   // std::set<std::string> semantics: sort + unique.  String order == numeric order of the key (most significant word
   // first: word nw-1 ... word 0).
-  typedef std::array<u64, 4> SeedKey;
-  std::vector<SeedKey> v;
-  v.reserve(c->n_reads);
-  for (u64 r = 0; r < c->n_reads; r++) {
-    if (!hv[r]) continue;
-    SeedKey kk = {0, 0, 0, 0};
-    for (int j = 0; j < nw; j++) kk[j] = h[r * nw + (nw - 1 - j)];  // kk[0] is compared first: the top word
-    v.push_back(kk);
-  }
-  std::sort(v.begin(), v.end());
-  v.erase(std::unique(v.begin(), v.end()), v.end());
-  *n = v.size();
-  if (cap < v.size()) return fail(c, P3_ECAPACITY, "need %zu seed slots", v.size());
-  if (v.size() && !fwd_keys) return fail(c, P3_EBADARG, "null output");
-  for (size_t i = 0; i < v.size(); i++)
-    for (int j = 0; j < nw; j++) fwd_keys[i * nw + (nw - 1 - j)] = v[i][j];
+  std::vector<u64> order;
+  order.reserve(c->n_reads);
+  for (u64 r = 0; r < c->n_reads; r++)
+    if (hv[r]) order.push_back(r);
+  auto key_cmp = [&](u64 a, u64 b) {  // <0, 0, >0 from the top word down
+    for (int j = nw - 1; j >= 0; j--)
+      if (h[a * nw + j] != h[b * nw + j]) return h[a * nw + j] < h[b * nw + j] ? -1 : 1;
+    return 0;
+  };
+  std::sort(order.begin(), order.end(), [&](u64 a, u64 b) { return key_cmp(a, b) < 0; });
+  order.erase(std::unique(order.begin(), order.end(), [&](u64 a, u64 b) { return key_cmp(a, b) == 0; }), order.end());
+  *n = order.size();
+  if (cap < order.size()) return fail(c, P3_ECAPACITY, "need %zu seed slots", order.size());
+  if (order.size() && !fwd_keys) return fail(c, P3_EBADARG, "null output");
+  for (size_t i = 0; i < order.size(); i++)
+    for (int j = 0; j < nw; j++) fwd_keys[i * nw + j] = h[order[i] * nw + j];
   return P3_OK;
 }
 
@@ -762,6 +774,9 @@ int p3_bloom_query(p3_ctx* c, const uint64_t* keys, uint64_t n, uint8_t* out) {
                          c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
     else if (nw == 4)
       hipLaunchKernelGGL((k_wide_query<4>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
+                         c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
+    else if (nw > 4)
+      hipLaunchKernelGGL(k_long_query, dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,
                          c->H, (const u32*)c->bloom.p, (uint8_t*)dout.p);
     else
       hipLaunchKernelGGL((k_bloom_query<2>), dim3(grid_for(n)), dim3(256), 0, c->stream, (const u64*)dk.p, n, c->k, mm,

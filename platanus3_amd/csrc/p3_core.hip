@@ -180,7 +180,7 @@ int do_pack(p3_ctx* c) {
 
 // every stage takes k in 21..128 (one to four key words)
 int check_k(p3_ctx* c, u32 k) {
-  if (k < 21 || k > 128) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,128]", k);
+  if (k < 21 || k > P3_LONG_MAX_K) return fail(c, P3_EUNSUPPORTED_K, "k=%u outside [21,%u]", k, P3_LONG_MAX_K);
   return P3_OK;
 }
 

@@ -33,6 +33,7 @@
 #include "p3_kernels_sk.h"
 #include "p3_kernels_seedset.h"
 #include "p3_kernels_wide.h"
+#include "p3_kernels_long.h"
 
 struct KStat {
   std::string name;

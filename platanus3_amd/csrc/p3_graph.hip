@@ -273,6 +273,7 @@ int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_mr_build_graph before p3_mr_run_pass");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
+  if (nw_of(c->k) > 4) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes keys of up to four words (k <= 128), k=%u", c->k);
   int rc;
   switch (nw_of(c->k)) {
     case 1: rc = mr_build_graph_t<1>(c, cm); break;
@@ -289,6 +290,7 @@ int p3_build_graph(p3_ctx* c) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
+  if (nw_of(c->k) > 4) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes keys of up to four words (k <= 128), k=%u", c->k);
   switch (nw_of(c->k)) {
     case 1: return build_graph_t<1>(c);
     case 2: return build_graph_t<2>(c);

@@ -80,8 +80,10 @@ int main(int argc, char** argv) {
       case 51: return run<std::bitset<102>>(rf, k, m, H, argv[5]);
       case 61: return run<std::bitset<122>>(rf, k, m, H, argv[5]);
       case 63: return run<std::bitset<126>>(rf, k, m, H, argv[5]);
-      case 101: return run<std::bitset<202>>(rf, k, m, H, argv[5]);  // (count + Bloom + seeds; the graph stage takes k <= 64)
-      default: std::cerr << "demo dispatches k in {21,25,31,41,51,61,63,101}\n"; return 1;
+      case 101: return run<std::bitset<202>>(rf, k, m, H, argv[5]);  // (count + Bloom + seeds)
+      case 501: return run<std::bitset<1002>>(rf, k, m, H, argv[5]);  // (the reference's long-read cases, src/Assemble.cpp:42-49:
+      case 1001: return run<std::bitset<2002>>(rf, k, m, H, argv[5]);  //  count + Bloom + seeds)
+      default: std::cerr << "demo dispatches k in {21,25,31,41,51,61,63,101,501,1001}\n"; return 1;
     }
   } catch (const std::exception& e) {
     std::cerr << "error: " << e.what() << "\n";

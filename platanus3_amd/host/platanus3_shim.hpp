@@ -12,7 +12,8 @@
 // the classes are re-declared with the reference's member names and filled from the flat results of the ABI.
 //
 // Differences a maintainer should know:
-//   * k in [21,128] (one to four key words; the reference's k = 101 included); unsupported k throws (the reference's
+//   * k in [21,128] (one to four key words; the reference's k = 101 included) for the whole Assemble sequence, k up to the
+//     reference's 3001 for CountShortKmer + MakeBF (the de Bruijn stage stops at four words); unsupported k throws (the reference's
 //     Assemble_k silently returns 1, src/Assemble.cpp:51-52);
 //   * materialising the STL containers (17.7 M unordered_map inserts at config #2) costs seconds of host
 //     time -- callers that can consume flat arrays should use the C ABI directly;
@@ -393,7 +394,7 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
                         std::set<std::string>* seed_kmer, Logging& logging) {
   (void)logging;
   if (LARGE_BITSET().size() != (size_t)(2 * kmer_length)) throw std::invalid_argument("MakeBF: bitset width != 2k");
-  if (kmer_length < 21 || kmer_length > 128) throw std::invalid_argument("MakeBF: k outside [21,128]");
+  if (kmer_length < 21 || kmer_length > 3001) throw std::invalid_argument("MakeBF: k outside [21,3001]");
   p3shim::Session& s = p3shim::Session::get();
   p3_ctx* ctx = s.context();
   // The device-resident count table is reused when CountShortKmer was just run on the same ReadSet; KC itself

@@ -1,0 +1,147 @@
+"""GPU tier: keys of five words and more (129 <= k <= 3001; the reference's long-read cases k = 501, 1001, 3001,
+src/Assemble.cpp:42-49) through the C ABI -- count, gate, Bloom vector, seeds, BF::query -- against golden vectors from
+the REAL reference (tests/golden/long.json) and against the oracle on random reads.  The de Bruijn stage stops at four
+words (k <= 128): P3_EUNSUPPORTED_K beyond."""
+import hashlib
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import platanus3_amd.synth as synth
+from platanus3_amd import capi
+from tests.golden.make_golden_long import KS, read_set
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "long.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).view(np.uint8).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", ["long4k", "long1k5", "ragged_long"])
+def test_pass_against_reference_goldens(name):
+    b, o = read_set(name)
+    cases = [g for g in GOLD["reads"] if g["set"] == name]
+    assert {g["k"] for g in cases} == set(KS)
+    ctx = capi.Context(0)
+    try:
+        last_k = None
+        for g in cases:
+            k = g["k"]
+            if k != last_k:
+                ctx.load_reads(b, o, min_len=k)
+                last_k = k
+            ctx.run_pass(k, g["m"], g["H"])
+            assert ctx.count_stats()["n_distinct"] == g["n_distinct_21"]
+            words = ctx.export_bloom()
+            assert int(np.unpackbits(words.view(np.uint8)).sum()) == g["bits_set"], (name, k, g["m"])
+            assert sha(words) == g["bloom_sha256"], (name, k, g["m"])
+            seeds = [capi.decode_key(x, k) for x in ctx.export_seeds()]
+            assert len(seeds) == g["n_seeds"]
+            assert hashlib.sha256("".join(seeds).encode()).hexdigest() == g["seeds_sha256"]
+    finally:
+        ctx.close()
+
+
+def _random_reads(rng, n, max_len, genome_len=12000, unknown=0.15):
+    genome = rng.choice(list(b"ACGT"), genome_len).astype(np.uint8)
+    reads = []
+    for _ in range(n):
+        L = int(rng.randint(0, max_len))
+        a = int(rng.randint(0, genome_len - max_len))
+        r = genome[a:a + L].copy()
+        if L and rng.rand() < unknown:
+            r[rng.randint(0, L)] = ord("N")
+        if L > 3 and rng.rand() < 0.3:
+            r[rng.randint(0, L)] = rng.choice(list(b"ACGT"))  # a substitution: windows that fail the gate
+        reads.append(r.tobytes())
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    return bases, offs
+
+
+def test_random_reads_against_oracle(oracle):
+    """any k in 129 .. 3001 (word-boundary cases of the top word included), both gates, BF::query on the result"""
+    rng = np.random.RandomState(21)
+    ctx = capi.Context(0)
+    try:
+        for trial in range(14):
+            k = int(rng.choice([129, 130, 159, 160, 161, 192, 255, 256, 257, 320, 501, 777, 1001, 1024, 2001, 3000, 3001]))
+            b, o = _random_reads(rng, int(rng.randint(30, 160)), int(min(11000, 3 * k + 300)))
+            m, H = int(rng.randint(20000, 3000000)), int(rng.randint(1, 20))
+            ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+            ewords, eseeds, n_ins, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+            ctx.load_reads(b, o, min_len=k)
+            for gate in (2, 1):
+                ctx.set_option("gate_mode", gate)
+                ctx.run_pass(k, m, H)
+                assert np.array_equal(ctx.export_bloom(), ewords), (trial, k, gate)
+                assert [capi.decode_key(x, k) for x in ctx.export_seeds()] == eseeds, (trial, k, gate)
+                assert ctx.bloom_stats()["n_passing"] == n_ins
+            ctx.set_option("gate_mode", 0)
+            nw = capi.nwords(k)
+            top = 2 * k - 64 * (nw - 1)
+            q = rng.randint(0, 1 << 62, size=(32, nw)).astype(np.uint64)
+            q[:, nw - 1] &= np.uint64((1 << top) - 1) if top < 64 else np.uint64(2**64 - 1)
+            if eseeds:
+                canon = np.stack([oracle.canonical(oracle.encode_fwd(s), oracle.encode_rc(s), k) for s in eseeds[:16]])
+                q = np.concatenate([q, canon])
+            got = ctx.bloom_query(q.reshape(-1))
+            assert np.array_equal(got, oracle.bloom_query(ewords, m, H, q.reshape(-1), k))
+            if eseeds:
+                assert got[32:].all()
+    finally:
+        ctx.close()
+
+
+def test_the_graph_stage_stops_at_four_words():
+    b, o = read_set("long1k5")
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(b, o, min_len=129)
+        ctx.run_pass(129, 1 << 22, 7)
+        with pytest.raises(capi.P3Error) as e:
+            ctx.build_graph()
+        assert e.value.code == 2  # P3_EUNSUPPORTED_K
+    finally:
+        ctx.close()
+
+
+def test_sharded_pass_with_long_keys(oracle):
+    """k = 501 over two protocol ranks on one GPU (p3_group): partial vectors OR-merged, seeds per rank"""
+    k, V = 501, 2
+    b, o = synth.reads(seed=86, total_reads=400, read_len=2000, sub_rate_ppm=1000)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+    ewords, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+    grp = capi.Group(V, None)
+    per = 400 // V
+    res, errors = [None] * V, []
+
+    def worker(i):
+        try:
+            comm = capi.Comm.member(grp, i)
+            ctx = capi.Context(0)
+            ctx.load_reads(b[int(o[i * per]):int(o[(i + 1) * per])], o[i * per:(i + 1) * per + 1] - o[i * per], min_len=k)
+            ctx.mr_run_pass(comm, k, m, H)
+            res[i] = (ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            ctx.close()
+            comm.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(V)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    grp.close()
+    assert not errors, errors
+    for words, _ in res:
+        assert np.array_equal(words, ewords)
+    assert sorted(set(s for _, sd in res for s in sd)) == eseeds

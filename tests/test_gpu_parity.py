@@ -167,7 +167,7 @@ def test_error_codes(ctx):
     b, o = synth.reads(seed=1, total_reads=50, read_len=100)
     ctx.load_reads(b, o, min_len=31)
     ctx.count_short()
-    for bad_k in (5, 20, 129, 501):
+    for bad_k in (5, 20, 3002, 5001):
         with pytest.raises(capi.P3Error) as e:
             ctx.make_bloom(bad_k, 1000, 3)
         assert e.value.code == 2  # P3_EUNSUPPORTED_K (the reference silently returns 1)

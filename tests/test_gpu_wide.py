@@ -114,13 +114,13 @@ def test_every_wide_k_on_one_read_set(oracle):
         ctx.close()
 
 
-def test_k_beyond_four_words_is_refused():
+def test_k_beyond_the_widest_dispatch_is_refused():
     b, o = synth.reads(seed=75, total_reads=300, read_len=200)
     ctx = capi.Context(0)
     try:
         ctx.load_reads(b, o, min_len=101)
         with pytest.raises(capi.P3Error) as e:
-            ctx.run_pass(129, 1 << 22, 7)
+            ctx.run_pass(3002, 1 << 22, 7)   # (the reference's widest case is k = 3001, src/Assemble.cpp:48)
         assert e.value.code == 2  # P3_EUNSUPPORTED_K
     finally:
         ctx.close()

@@ -80,6 +80,30 @@ def test_shim_k101_matches_reference_golden(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [501, 1001])
+def test_shim_long_keys_match_reference_golden(tmp_path, k):
+    """MakeBF<std::bitset<1002>> / <2002> -- the reference's long-read cases (src/Assemble.cpp:42-45) -- through the shim,
+    against the real reference's vector and seed set (tests/golden/long.json)"""
+    import hashlib
+    import json
+    from tests.golden.make_golden_long import read_set
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "long.json")))
+    g = [c for c in gold["reads"] if c["set"] == "long4k" and c["k"] == k][0]
+    b, o = read_set("long4k")
+    exe = _compile(tmp_path)
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(o.size - 1):
+            f.write(">r%d\n%s\n" % (i, bytes(b[int(o[i]):int(o[i + 1])]).decode()))
+    out = os.path.join(str(tmp_path), "out")
+    subprocess.check_call([exe, fa, str(k), str(g["m"]), str(g["H"]), out], cwd=str(tmp_path), timeout=120)
+    words = np.fromfile(out + ".bloom", dtype=np.uint64)
+    assert hashlib.sha256(words.tobytes()).hexdigest() == g["bloom_sha256"]
+    seeds = [s for s in open(out + ".seeds").read().split("\n") if s]
+    assert len(seeds) == g["n_seeds"] and hashlib.sha256("".join(seeds).encode()).hexdigest() == g["seeds_sha256"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["synth2000_k31", "synth1000_k41", "long40_k63"])
 def test_shim_full_assemble_gfa(tmp_path, name):
     """The whole Assemble<B> sequence through the shim (CountShortKmer, MakeBF, DeBruijnGraph::MakeDBG,
