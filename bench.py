@@ -283,7 +283,7 @@ def main():
             v1 = per_k[0]["value"]
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "traffic_note": "PMC estimate (FETCH_SIZE x2 for wide streaming reads applied per kernel by hand)",
+                    "traffic_note": "rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch; the x2 is calibrated with known-size microkernels (profiles/r02_pmc_calibration.json: 0.500 of the bytes read are reported for every coalesced shape, writes are exact)",
                     "avg_launch_ms": avg_ms, "alg_bytes_per_launch": per_launch_bytes,
                     "pass_alg_bytes_per_kmer": b_alg_kmer,
                     "pass_frac": (v1 / world) * b_alg_kmer / (HBM_PEAK_GBS * 1e9),
