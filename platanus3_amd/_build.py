@@ -70,6 +70,16 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+def build_tools(force=False):
+    """the measurement helper that is HIP code too: tools/pmc_calib (known-size access shapes for the PMC counters)"""
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    src, exe = os.path.join(tools, "pmc_calib.hip"), os.path.join(tools, "pmc_calib")
+    if os.path.exists(src) and (force or _newer(exe, [src])):
+        subprocess.check_call([hipcc_path(), "--offload-arch=gfx950", "-O2", "-o", exe, src])
+    return exe
+
+
 def build_all(force=False):
     build_synth(force)
     build_lib(force)
+    build_tools(force)
