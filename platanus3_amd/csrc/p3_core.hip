@@ -233,7 +233,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
                     &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps, &c->unk_flag,
                     &c->seed_part, &c->seed_hist, &c->seed_set, &c->seed_ucount, &c->seed_flag, &c->g_jtcov, &c->xc_buf,
-                    &c->xg_buf, &c->g_k2, &c->g_k3, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3]};
+                    &c->xg_buf, &c->g_k2, &c->g_k3, &c->g_kx, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3]};
   for (DevBuf* b : bufs) release(*b);
   free_outgrown(c);
   for (auto& ev : c->ev)

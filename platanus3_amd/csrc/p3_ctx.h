@@ -166,7 +166,7 @@ struct p3_ctx {
   u64 sing_count[P3_MAX_RANKS] = {0};
   bool s_ready = false;
   // de Bruijn stage
-  DevBuf g_klo, g_khi, g_k2, g_k3, g_info, g_nid, g_f0, g_f1, g_ctr, g_jcov, g_jtcov, g_runs, g_seqoff, g_seq, g_edges, g_jkeys;
+  DevBuf g_klo, g_khi, g_k2, g_k3, g_kx, g_info, g_nid, g_f0, g_f1, g_ctr, g_jcov, g_jtcov, g_runs, g_seqoff, g_seq, g_edges, g_jkeys;
   u64 g_cap = 0;
   bool graphed = false;
   p3_graph_stats gstats_{};

@@ -22,8 +22,8 @@ DbgParams graph_params(const p3_ctx* c) {
 }
 
 DbgTab graph_table(const p3_ctx* c) {
-  return DbgTab{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u32*)c->g_info.p, (u32*)c->g_nid.p,
-                c->g_cap - 1};
+  return DbgTab{{(u64*)c->g_klo.p, (u64*)c->g_khi.p, (u64*)c->g_k2.p, (u64*)c->g_k3.p}, (u64*)c->g_kx.p, (u32*)c->g_info.p,
+                (u32*)c->g_nid.p, c->g_cap - 1};
 }
 
 // table buffers for `cap` slots (the frontier buffers only where the closure runs)
@@ -31,8 +31,9 @@ template <int NW>
 int graph_alloc_table(p3_ctx* c, u64 cap) {
   int rc;
   DevBuf* kbuf[4] = {&c->g_klo, &c->g_khi, &c->g_k2, &c->g_k3};
-  for (int j = 0; j < NW; j++)
+  for (int j = 0; j < NW && j < 4; j++)
     if ((rc = ensure(c, *kbuf[j], cap * 8))) return rc;
+  if (NW > 4 && (rc = ensure(c, c->g_kx, cap * 8 * (NW - 4)))) return rc;
   if ((rc = ensure(c, c->g_info, cap * 4))) return rc;
   if ((rc = ensure(c, c->g_nid, cap * 4))) return rc;
   c->g_cap = cap;
@@ -266,6 +267,13 @@ int mr_build_graph_t(p3_ctx* c, p3_comm* cm) {
 
 }  // namespace
 
+// The graph kernels are instantiated for keys of one to four words (every k <= 128) and for the word counts of the
+// reference's long-read cases (src/Assemble.cpp:42-49): 16, 32, 63, 94 words = k in 481..512, 993..1024, 1985..2016, 2977..3001.
+static int graph_width_unsupported(p3_ctx* c) {
+  return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage is built for k <= 128 and for keys of 16, 32, 63 or 94 words "
+                                    "(k = 501, 1001, 2001, 3001 and their neighbours), k=%u", c->k);
+}
+
 extern "C" {
 
 int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
@@ -273,13 +281,17 @@ int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_mr_build_graph before p3_mr_run_pass");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
-  if (nw_of(c->k) > 4) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes keys of up to four words (k <= 128), k=%u", c->k);
   int rc;
   switch (nw_of(c->k)) {
     case 1: rc = mr_build_graph_t<1>(c, cm); break;
     case 2: rc = mr_build_graph_t<2>(c, cm); break;
     case 3: rc = mr_build_graph_t<3>(c, cm); break;
-    default: rc = mr_build_graph_t<4>(c, cm); break;
+    case 4: rc = mr_build_graph_t<4>(c, cm); break;
+    case 16: rc = mr_build_graph_t<16>(c, cm); break;
+    case 32: rc = mr_build_graph_t<32>(c, cm); break;
+    case 63: rc = mr_build_graph_t<63>(c, cm); break;
+    case 94: rc = mr_build_graph_t<94>(c, cm); break;
+    default: rc = graph_width_unsupported(c); break;
   }
   if (rc) xc_abort(cm);
   return rc;
@@ -290,12 +302,16 @@ int p3_build_graph(p3_ctx* c) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
-  if (nw_of(c->k) > 4) return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage takes keys of up to four words (k <= 128), k=%u", c->k);
   switch (nw_of(c->k)) {
     case 1: return build_graph_t<1>(c);
     case 2: return build_graph_t<2>(c);
     case 3: return build_graph_t<3>(c);
-    default: return build_graph_t<4>(c);
+    case 4: return build_graph_t<4>(c);
+    case 16: return build_graph_t<16>(c);
+    case 32: return build_graph_t<32>(c);
+    case 63: return build_graph_t<63>(c);
+    case 94: return build_graph_t<94>(c);
+    default: return graph_width_unsupported(c);
   }
 }
 

@@ -18,6 +18,7 @@
 #pragma once
 #include "p3_kernels_retgate.h"
 #include "p3_kernels_wide.h"
+#include "p3_kernels_long.h"
 
 #define DBG_FULL (1u << 8)
 #define DBG_JUNCTION (1u << 9)
@@ -31,7 +32,8 @@
 #define DBG_BUSY (1u << 30)
 #define DBG_NOSLOT (~0ULL)
 
-// A key = NW 64-bit words, word 0 least significant (1 <= NW <= 4: k <= 128)
+// A key = NW 64-bit words, word 0 least significant (1 <= NW <= 4: k <= 128; and the widths of the reference's long-read
+// cases k = 501, 1001, 2001, 3001: NW = 16, 32, 63, 94 -- the same templates, the keys then live in scratch memory)
 template <int NW>
 struct DKey {
   u64 w[NW];
@@ -39,10 +41,14 @@ struct DKey {
 
 struct DbgTab {
   u64* kw[4];  // key words, one array per word (kw[1..3] only for NW >= 2, 3, 4)
+  u64* kwx;    // words 4 .. NW-1 of the wide forms: word j of slot s at kwx[(j - 4) * (cap_mask + 1) + s]
   u32* info;
   u32* nid;
   u64 cap_mask;
 };
+__device__ __forceinline__ u64& tab_word(const DbgTab& t, int j, u64 slot) {
+  return j < 4 ? t.kw[j][slot] : t.kwx[(u64)(j - 4) * (t.cap_mask + 1) + slot];
+}
 
 struct DbgParams {
   u32 k, H;
@@ -171,7 +177,7 @@ template <int NW>
 __device__ __forceinline__ DKey<NW> tab_key(const DbgTab& t, u64 slot) {
   DKey<NW> o;
 #pragma unroll
-  for (int j = 0; j < NW; j++) o.w[j] = t.kw[j][slot];
+  for (int j = 0; j < NW; j++) o.w[j] = tab_word(t, j, slot);
   return o;
 }
 
@@ -220,7 +226,7 @@ __device__ __forceinline__ bool node_insert(const DbgTab& t, const DKey<NW>& c, 
       if (st == 0) {
         if (atomicCAS(&t.info[slot], 0u, DBG_BUSY) == 0u) {
 #pragma unroll
-          for (int j = 0; j < NW; j++) t.kw[j][slot] = c.w[j];
+          for (int j = 0; j < NW; j++) tab_word(t, j, slot) = c.w[j];
           __hip_atomic_store(&t.info[slot], DBG_BUSY | DBG_KEYED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
           out_slot = slot;
           return true;
@@ -414,7 +420,7 @@ static __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __rest
   if (!(t.info[s] & DBG_JUNCTION)) return;
   const u64 id = t.nid[s];
 #pragma unroll
-  for (int j = 0; j < NW; j++) jkeys[id * NW + j] = t.kw[j][s];
+  for (int j = 0; j < NW; j++) jkeys[id * NW + j] = tab_word(t, j, s);
 }
 
 // ---- k_dbg_coverage ------------------------------------------------------------------------------------------------
@@ -483,6 +489,29 @@ static __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restri
         }
         kr.roll();
         shr128(L.Elo, L.Ehi);
+      }
+    } else if constexpr (NW > 4) {
+      // keys of any width (p3_kernels_long.h): validity is the word's own end bits + one run length; the key words of a
+      // valid window are read from the packed streams
+      const u32 Ew = endm[w];
+      if (Ew == 0xffffffffu) continue;
+      const u32 n_e = p.k - 1;
+      const u32 clear = long_run<false>(endm, w + 1, n_words + P3_PAD_WORDS, n_e);
+      for (u32 j = 0; j < 32; j++) {
+        if ((Ew >> j) != 0 || clear < j + n_e - 32) continue;
+        LongKey lk;
+        lk.fw = fw;
+        lk.rcw = rcw;
+        lk.b0 = 2 * ((w << 5) + j);
+        lk.s = 2 * p.k;
+        lk.nw = NW;
+        lk.top_bits = p.top_bits;
+        DKey<NW> f, r;
+        for (int q = 0; q < NW; q++) {
+          f.w[q] = lk.fwd((u32)q);
+          r.w[q] = lk.rc((u32)q);
+        }
+        dbg_cover_window<NW>(f, r, (w << 5) + j, endm, bases, n_bases, t, p, jcov, jtcov);
       }
     } else {
       const u32 validk = ~wide_win32<false>(b192_load(endm, w), p.k - 1);  // no read end in [pos, pos + k - 1)

@@ -42,7 +42,7 @@ struct Run {
     const int n_gpus = gpus && *gpus ? std::atoi(gpus) : 0;
     const int status = n_gpus > 0 ? AssembleSharded(reads, opt, log, n_gpus)
                        : (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
-    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..128)\n";
+    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..128, 501, 1001, 2001, 3001)\n";
     log.WriteLog("finish");
     return status == 0 ? 0 : 3;
   }

@@ -557,9 +557,9 @@ class DeBruijnGraph {
   std::vector<int32_t> cov_, lcov_, rcov_;
   static LARGE_BITSET to_bitset(const uint64_t* w, int nw) {
     LARGE_BITSET b(w[0]);
-    if (nw == 2) {
-      LARGE_BITSET hi(w[1]);
-      b |= (hi << 64);
+    for (int j = 1; j < nw; j++) {  // (keys of any width: word j at bit 64 j)
+      LARGE_BITSET wj(w[j]);
+      b |= (wj << (64 * (size_t)j));
     }
     return b;
   }
@@ -599,9 +599,18 @@ int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
 // Same steps, same log lines, same output file as Assemble<B> above, but nothing is copied back to the host between
 // the stages: the count table, the Bloom vector, the seeds and the graph stay in HBM from p3_load_reads to
 // p3_write_gfa (the command line has no use for KmerCount / BF::m_bits / the three graph maps -- filling them is
-// 9 of the 10 s of a 1 M-read run).  k is checked by the library (21..128); other k return 1 like Assemble_k.
+// 9 of the 10 s of a 1 M-read run).  k: AssembleTakes (21..128 and the reference's 501, 1001, 2001, 3001); other k return 1
+// like Assemble_k.
+// the k the whole sequence (graph stage included) takes: 21..128, and the key widths of the reference's long-read cases --
+// 16, 32, 63 or 94 words: k = 501, 1001, 2001, 3001 and their neighbours (p3_build_graph)
+inline bool AssembleTakes(int k) {
+  if (k >= 21 && k <= 128) return true;
+  const int nw = (2 * k + 63) / 64;
+  return k <= 3001 && (nw == 16 || nw == 32 || nw == 63 || nw == 94);
+}
+
 inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& logging) {
-  if (options.kmer_length < 21 || options.kmer_length > 128) return 1;
+  if (!AssembleTakes(options.kmer_length)) return 1;
   logging.WriteLog("Assemble");
   p3shim::Session& s = p3shim::Session::get();
   s.load(input_reads.reads, options.kmer_length);
@@ -633,7 +642,7 @@ inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& lo
 // CountShortKmer + MakeBF over all shards, p3_mr_build_graph the de Bruijn stage (structure on rank 0, coverage of every
 // shard summed); rank 0 writes the GFA.  Same log lines as Assemble.  n_gpus = 1 is AssembleResident through the same path.
 inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& logging, int n_gpus) {
-  if (options.kmer_length < 21 || options.kmer_length > 128) return 1;
+  if (!AssembleTakes(options.kmer_length)) return 1;
   if (n_gpus < 1 || n_gpus > p3_device_count() || 1024 % n_gpus != 0)
     throw std::invalid_argument("AssembleSharded: " + std::to_string(n_gpus) + " GPUs asked for, " + std::to_string(p3_device_count()) +
                                 " present (the count must divide 1024)");
@@ -705,9 +714,9 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
   return 0;
 }
 
-// Every one- and two-word k (21..64) is dispatched, and the reference's own k = 101 (four words) -- the reference's
-// switch (src/Assemble.cpp:31-53) has 21, 25, 63 and 101 in the supported range; like there, any other k returns 1
-// without doing anything.  (AssembleResident takes every k in 21..128: it needs no std::bitset instance.)
+// Every one- and two-word k (21..64) is dispatched, and the reference's own k = 101, 501, 1001, 2001, 3001 -- the
+// reference's switch (src/Assemble.cpp:31-53) has 21, 25, 63 and those five in the supported range; like there, any other
+// k returns 1 without doing anything.  (AssembleResident takes every k in 21..128 as well: it needs no std::bitset instance.)
 inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging) {
   switch (options.kmer_length) {
 #define P3SHIM_CASE(K) \
@@ -719,7 +728,7 @@ inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging)
     P3SHIM_CASE(42) P3SHIM_CASE(43) P3SHIM_CASE(44) P3SHIM_CASE(45) P3SHIM_CASE(46) P3SHIM_CASE(47) P3SHIM_CASE(48)
     P3SHIM_CASE(49) P3SHIM_CASE(50) P3SHIM_CASE(51) P3SHIM_CASE(52) P3SHIM_CASE(53) P3SHIM_CASE(54) P3SHIM_CASE(55)
     P3SHIM_CASE(56) P3SHIM_CASE(57) P3SHIM_CASE(58) P3SHIM_CASE(59) P3SHIM_CASE(60) P3SHIM_CASE(61) P3SHIM_CASE(62)
-    P3SHIM_CASE(63) P3SHIM_CASE(64) P3SHIM_CASE(101)
+    P3SHIM_CASE(63) P3SHIM_CASE(64) P3SHIM_CASE(101) P3SHIM_CASE(501) P3SHIM_CASE(1001) P3SHIM_CASE(2001) P3SHIM_CASE(3001)
 #undef P3SHIM_CASE
     default:
       return 1;

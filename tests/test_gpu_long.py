@@ -1,7 +1,7 @@
 """GPU tier: keys of five words and more (129 <= k <= 3001; the reference's long-read cases k = 501, 1001, 3001,
 src/Assemble.cpp:42-49) through the C ABI -- count, gate, Bloom vector, seeds, BF::query -- against golden vectors from
-the REAL reference (tests/golden/long.json) and against the oracle on random reads.  The de Bruijn stage stops at four
-words (k <= 128): P3_EUNSUPPORTED_K beyond."""
+the REAL reference (tests/golden/long.json) and against the oracle on random reads; the de Bruijn stage at the reference's
+own widths (k = 501, 1001, 2001, 3001) against the reference's GFA (tests/golden/dbgl_*)."""
 import hashlib
 import json
 import os
@@ -99,15 +99,53 @@ def test_random_reads_against_oracle(oracle):
         ctx.close()
 
 
-def test_the_graph_stage_stops_at_four_words():
+def test_the_graph_stage_takes_the_reference_widths_only():
+    """p3_build_graph: every k <= 128 and the word counts of the reference's long-read cases (16, 32, 63, 94 words)"""
     b, o = read_set("long1k5")
     ctx = capi.Context(0)
     try:
         ctx.load_reads(b, o, min_len=129)
-        ctx.run_pass(129, 1 << 22, 7)
+        ctx.run_pass(129, 1 << 22, 7)   # five words
         with pytest.raises(capi.P3Error) as e:
             ctx.build_graph()
         assert e.value.code == 2  # P3_EUNSUPPORTED_K
+    finally:
+        ctx.close()
+
+
+def _dbgl_cases():
+    p = os.path.join(os.path.dirname(__file__), "golden", "dbgl_cases.json")
+    return json.load(open(p)) if os.path.exists(p) else []
+
+
+@pytest.mark.parametrize("case", _dbgl_cases(), ids=lambda c: c["name"])
+def test_long_graph_matches_reference_gfa(tmp_path, case):
+    """MakeDBG + CountNodeCoverage + PrintGraph at k = 501, 1001, 2001, 3001 against the REAL reference's GFA (-t 1) in
+    ID-free canonical form, and JointInfo::coverage against what the reference accumulated
+    (tests/golden/make_golden_dbg_long.py)"""
+    import gzip
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "dbgl_%s_reads.npz" % case["name"]))
+    k = case["k"]
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(z["bases"], z["offsets"], min_len=k)
+        ctx.run_pass(k, case["m"], case["H"])
+        st = ctx.build_graph()
+        assert st["n_junctions"] == case["n_junctions"] and st["n_straights"] == case["n_straights"]
+        path = os.path.join(str(tmp_path), "g.gfa")
+        ctx.write_gfa(path)
+        nodes, edges = canonical(open(path).read())
+        ls = canon_lines(nodes, edges)
+        with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "dbgl_%s.canon.gz" % case["name"]), "rt") as f:
+            assert ls == f.read().split("\n")
+        assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
+        joints = ctx.joint_coverage()
+        jl = ["%s\t%d" % (a, b) for a, b in joints]
+        g = case["joints"]
+        assert len(joints) == g["n"] and sum(b for _, b in joints) == g["coverage_sum"]
+        assert hashlib.sha256("\n".join(jl).encode()).hexdigest() == g["sha256"]
     finally:
         ctx.close()
 

@@ -127,3 +127,33 @@ def test_shim_full_assemble_gfa(tmp_path, name):
     # JointInfo::coverage materialised into the shim's joints map == what the real reference accumulated
     gj = json.load(open(os.path.join(GOLDEN, "dbg_joints.json")))[name]
     assert njo == gj["n"] and jointsum == gj["coverage_sum"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prefix,name", [("dbgw", "synth1500_k101"), ("dbgl", "long120_k501"), ("dbgl", "long120_k1001")])
+def test_shim_full_assemble_gfa_wide_keys(tmp_path, prefix, name):
+    """Assemble<std::bitset<202>> / <1002> / <2002> through the shim, graph stage included (junction keys of 4, 16 and 32
+    words materialised into the reference's maps): the GFA equals the reference's in canonical form."""
+    import gzip
+    import hashlib
+    import json
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    from util import GOLDEN
+    cases = json.load(open(os.path.join(GOLDEN, prefix + "_cases.json")))
+    case = [c for c in cases if c["name"] == name][0]
+    z = np.load(os.path.join(GOLDEN, "%s_%s_reads.npz" % (prefix, name)))
+    b, off = z["bases"], z["offsets"]
+    exe = _compile(tmp_path)
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(off.size - 1):
+            f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
+    out = os.path.join(str(tmp_path), "out")
+    subprocess.check_call([exe, fa, str(case["k"]), str(case["m"]), str(case["H"]), out, "graph"], cwd=str(tmp_path),
+                          timeout=300)
+    nodes, edges = canonical(open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
+    ls = canon_lines(nodes, edges)
+    with gzip.open(os.path.join(GOLDEN, "%s_%s.canon.gz" % (prefix, name)), "rt") as f:
+        assert ls == f.read().split("\n")
+    assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
