@@ -240,7 +240,8 @@ int mr_build_graph_t(p3_ctx* c, p3_comm* cm) {
       rn[0] = meta[1];
     DevBuf* kbuf[4] = {&c->g_klo, &c->g_khi, &c->g_k2, &c->g_k3};
     // (a rank sends from and receives into different halves of the call: rank 0 only sends, the others only receive)
-    for (int j = 0; j < NW; j++) XC(xc_a2av(cm, kbuf[j]->p, so, sc, kbuf[j]->p, ro, rn, 8, c->stream));
+    for (int j = 0; j < NW && j < 4; j++) XC(xc_a2av(cm, kbuf[j]->p, so, sc, kbuf[j]->p, ro, rn, 8, c->stream));
+    if (NW > 4) XC(xc_a2av(cm, c->g_kx.p, so, sc, c->g_kx.p, ro, rn, 8 * (NW - 4), c->stream));  // (words 4 .. NW-1, word-major)
     XC(xc_a2av(cm, c->g_info.p, so, sc, c->g_info.p, ro, rn, 4, c->stream));
     XC(xc_a2av(cm, c->g_nid.p, so, sc, c->g_nid.p, ro, rn, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

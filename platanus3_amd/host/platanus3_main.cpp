@@ -13,7 +13,7 @@
 // run over N GPUs of the node (AssembleSharded: one thread and one RCCL rank per GPU, same GFA).
 //
 // What differs from the reference binary, on purpose: every k in [21,128] is dispatched (its switch has only 21, 25,
-// 63 and 101 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
+// 63 and 101 in that range) besides its 501, 1001, 2001, 3001; a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
 // graph closure explodes, no GPU -- ends with a message on stderr and exit status 3 rather than a silent "finish".
 #include <cstdlib>
 

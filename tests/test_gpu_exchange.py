@@ -193,10 +193,12 @@ def test_run_pass_in_groups(oracle, procs, v, k, gate):
 
 
 @pytest.mark.parametrize("case_name,procs,v", [("synth2000_k31", 1, 4), ("synth3000_k51", 2, 2), ("long40_k63", 1, 2),
-                                                ("wide:synth1500_k101", 1, 4), ("wide:dense3000_k80", 2, 2)])
+                                                ("wide:synth1500_k101", 1, 4), ("wide:dense3000_k80", 2, 2),
+                                                ("long:dense300_k501", 1, 2), ("long:long40_k3001", 2, 2)])
 def test_sharded_graph_equals_reference_gfa(tmp_path, case_name, procs, v):
     """p3_mr_run_pass + p3_mr_build_graph over procs x v ranks (threads on this one GPU): rank 0's GFA against the REAL
-    reference's for the union of the reads (canonical form), JointInfo::coverage included -- one- to four-word keys"""
+    reference's for the union of the reads (canonical form), JointInfo::coverage included -- keys of one to four words and of
+    the reference's long-read widths (k = 501: 16 words, k = 3001: 94)"""
     import gzip
     import hashlib
     import json
@@ -204,9 +206,9 @@ def test_sharded_graph_equals_reference_gfa(tmp_path, case_name, procs, v):
     from gfa_canon import canonical
     from test_oracle_dbg import canon_lines
     golden = os.path.join(os.path.dirname(__file__), "golden")
-    wide = case_name.startswith("wide:")
+    wide = case_name.startswith("wide:") or case_name.startswith("long:")
     name = case_name.split(":")[-1]
-    prefix = "dbgw_" if wide else "dbg_"
+    prefix = "dbgl_" if case_name.startswith("long:") else "dbgw_" if wide else "dbg_"
     case = [c for c in json.load(open(os.path.join(golden, prefix + "cases.json"))) if c["name"] == name][0]
     z = np.load(os.path.join(golden, prefix + name + "_reads.npz"))
     b, o = z["bases"], z["offsets"]

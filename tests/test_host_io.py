@@ -155,20 +155,23 @@ def test_command_line_end_to_end(tmp_path_factory, tmp_path, name, materialise):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("materialise", [0, 1])
-@pytest.mark.parametrize("name", ["synth1500_k101", "long40_k127"])
+@pytest.mark.parametrize("name", ["synth1500_k101", "long40_k127", "dbgl:long120_k501", "dbgl:long40_k3001"])
 def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
-    """platanus3 -k 101 -- a case of the reference's own switch (src/Assemble.cpp:40) -- and -k 127: four-word keys through
-    the command line, GFA against the real reference's (tests/golden/dbgw_*).  The reference-typed containers
-    (PLATANUS3_MATERIALISE=1: Assemble<std::bitset<202>>) exist for k = 101 only, as in the reference."""
+    """platanus3 -k 101, -k 501, -k 3001 -- cases of the reference's own switch (src/Assemble.cpp:40-49) -- and -k 127: keys
+    of four, sixteen and ninety-four words through the command line, GFA against the real reference's
+    (tests/golden/dbgw_*, dbgl_*).  The reference-typed containers (PLATANUS3_MATERIALISE=1: Assemble<std::bitset<2k>>)
+    exist for the k the reference dispatches, as there."""
     import gzip
     import hashlib
     from gfa_canon import canonical
     from test_oracle_dbg import canon_lines
-    if materialise and name != "synth1500_k101":
-        pytest.skip("Assemble_k dispatches k = 101 of the wide keys")
-    case = [c for c in json.load(open(os.path.join(GOLDEN, "dbgw_cases.json"))) if c["name"] == name][0]
+    prefix = "dbgl" if name.startswith("dbgl:") else "dbgw"
+    name = name.split(":")[-1]
+    if materialise and name == "long40_k127":
+        pytest.skip("Assemble_k dispatches k = 101, 501, 1001, 2001, 3001 of the wide keys")
+    case = [c for c in json.load(open(os.path.join(GOLDEN, prefix + "_cases.json"))) if c["name"] == name][0]
     exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
-    z = np.load(os.path.join(GOLDEN, "dbgw_%s_reads.npz" % name))
+    z = np.load(os.path.join(GOLDEN, "%s_%s_reads.npz" % (prefix, name)))
     b, off = z["bases"], z["offsets"]
     fa = os.path.join(str(tmp_path), "reads.fasta")
     with open(fa, "w") as f:
@@ -179,7 +182,7 @@ def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
                           env=dict(os.environ, PLATANUS3_MATERIALISE=str(materialise)))
     nodes, edges = canonical(open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read())
     ls = canon_lines(nodes, edges)
-    with gzip.open(os.path.join(GOLDEN, "dbgw_%s.canon.gz" % name), "rt") as f:
+    with gzip.open(os.path.join(GOLDEN, "%s_%s.canon.gz" % (prefix, name)), "rt") as f:
         assert ls == f.read().split("\n")
     assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
     assert open(os.path.join(str(tmp_path), "platanus3.log")).read().rstrip().endswith("finish")
