@@ -13,7 +13,7 @@
  * are independent).  There is NO CPU fallback: without a usable HIP device every compute call fails
  * with P3_EHIP.
  *
- * Keys: a k-mer of 2k bits (21 <= k <= 3001; the de Bruijn stage: k <= 128 and keys of 16, 32, 63 or 94 words = k 501, 1001, 2001, 3001) is nw = (2k+63)/64 uint64 words, LOW word first -- the word
+ * Keys: a k-mer of 2k bits (21 <= k <= 3001: the reference's widest case) is nw = (2k+63)/64 uint64 words, LOW word first -- the word
  * order of libstdc++'s std::bitset<2k> that the reference uses as LARGE_BITSET.  Base codes A=0 C=1
  * G=2 T=3, first base in the most significant used bits (reference src/BitCalc.cpp:7-19).
  */
@@ -31,8 +31,8 @@ typedef struct p3_ctx p3_ctx;
 typedef enum {
   P3_OK = 0,
   P3_EBADARG = 1,         /* null pointer, zero size, inconsistent offsets ...            */
-  P3_EUNSUPPORTED_K = 2,  /* k outside [21,3001], or p3_build_graph at a key width it is not built for (the reference silently returns 1 for a k
-                           * it does not dispatch: src/Assemble.cpp:51-52) */
+  P3_EUNSUPPORTED_K = 2,  /* k outside [21,3001] (the reference silently returns 1 for a k it does not dispatch:
+                           * src/Assemble.cpp:51-52) */
   P3_ECAPACITY = 3,       /* caller buffer too small; the required size is still reported  */
   P3_EHIP = 4,            /* HIP runtime error / no device (see p3_last_error)             */
   P3_ECOMM = 5,           /* exchange step misuse (multi-rank protocol)                    */

@@ -39,7 +39,7 @@ namespace {
 // every supported large-k (1- and 2-word keys, and a few of the 3- and 4-word ones incl. the reference's own 101).  X(k)
 // (round 2: + widths beyond four words up to the reference's k = 501, 1001, 2001, 3001, src/Assemble.cpp:42-49)
 #define P3REF_KLIST(X) \
-  X(129) X(160) X(501) X(1001) X(2001) X(3001) \
+  X(129) X(160) X(501) X(600) X(1001) X(1500) X(2001) X(2500) X(3001) \
   X(65) X(80) X(96) X(97) X(101) X(127) X(128) \
   X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) \
   X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) \

@@ -16,7 +16,8 @@ DbgParams graph_params(const p3_ctx* c) {
   p.k = c->k;
   p.H = c->H;
   p.mm = make_modm(c->m);
-  p.top_bits = 2 * c->k - 64 * (NW - 1);  // 2 .. 64
+  p.nw = (u32)nw_of(c->k);                   // == NW for every k <= 128; the wide instances also take narrower keys
+  p.top_bits = 2 * c->k - 64 * (p.nw - 1);  // 2 .. 64
   p.mask_top = p.top_bits == 64 ? ~0ULL : ((1ULL << p.top_bits) - 1);
   return p;
 }
@@ -74,13 +75,14 @@ int graph_structure(p3_ctx* c, const u64* seed_keys, const uint8_t* seed_valid, 
     const u64* fin = seed_keys;
     const uint8_t* fvalid = seed_valid;
     u64 n_in = n_seeds_in;
+    u32 in_words = p.nw;  // the seeds carry the key's own words; the frontiers NW
     DevBuf* outb = &c->g_f0;
     bool overflow = false;
     levels = 0;
     while (n_in) {
       HIPCHK(c, hipMemsetAsync(ctr, 0, 8, c->stream));
-      LAUNCH(c, "k_dbg_expand", (k_dbg_expand<NW>), grid_for(n_in, 256, 1u << 30), 256, fin, fvalid, n_in, (u64*)outb->p,
-             fcap, t, (const u32*)c->bloom.p, p, node_limit, ctr);
+      LAUNCH(c, "k_dbg_expand", (k_dbg_expand<NW>), grid_for(n_in, 256, 1u << 30), 256, fin, fvalid, n_in, in_words,
+             (u64*)outb->p, fcap, t, (const u32*)c->bloom.p, p, node_limit, ctr);
       HIPCHK(c, hipMemcpyAsync(hc, ctr, 3 * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       if (hc[2]) {
@@ -88,6 +90,7 @@ int graph_structure(p3_ctx* c, const u64* seed_keys, const uint8_t* seed_valid, 
         break;
       }
       fin = (const u64*)outb->p;
+      in_words = NW;
       fvalid = nullptr;
       n_in = hc[0];
       outb = (outb == &c->g_f0) ? &c->g_f1 : &c->g_f0;
@@ -155,7 +158,7 @@ int graph_links(p3_ctx* c) {
   LAUNCH(c, "k_dbg_edges", (k_dbg_edges<NW>), grid_for(cap, 256, 1u << 30), 256, t, graph_params<NW>(c), (const u32*)c->bloom.p,
          (const u32*)c->g_jcov.p, (uint2*)c->g_edges.p, edge_cap, ctr);
   if ((rc = ensure(c, c->g_jkeys, (n_junc + 1) * 8 * NW))) return rc;
-  LAUNCH(c, "k_dbg_gather", (k_dbg_gather<NW>), grid_for(cap, 256, 1u << 30), 256, t, (u64*)c->g_jkeys.p);
+  LAUNCH(c, "k_dbg_gather", (k_dbg_gather<NW>), grid_for(cap, 256, 1u << 30), 256, t, (u32)nw_of(c->k), (u64*)c->g_jkeys.p);
   u64 hc[8];
   HIPCHK(c, hipMemcpyAsync(hc, ctr, 8 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -209,9 +212,10 @@ int mr_build_graph_t(p3_ctx* c, p3_comm* cm) {
       rcnt[s] = nreads[s];
       total += nreads[s];
     }
-  if ((rc = ensure(c, c->xg_buf, (total + 1) * 8 * NW))) return rc;
+  const u32 seed_bytes = 8 * (u32)nw_of(c->k);  // (the seeds carry the key's own words)
+  if ((rc = ensure(c, c->xg_buf, (total + 1) * seed_bytes))) return rc;
   if ((rc = ensure(c, c->or_tmp, total + 16))) return rc;
-  XC(xc_a2av(cm, c->seeds.p, soff, scnt, c->xg_buf.p, roff, rcnt, 8 * NW, c->stream));
+  XC(xc_a2av(cm, c->seeds.p, soff, scnt, c->xg_buf.p, roff, rcnt, seed_bytes, c->stream));
   XC(xc_a2av(cm, c->seed_valid.p, soff, scnt, c->or_tmp.p, roff, rcnt, 1, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // ---- structure on rank 0; its verdict and sizes to everybody
@@ -268,11 +272,12 @@ int mr_build_graph_t(p3_ctx* c, p3_comm* cm) {
 
 }  // namespace
 
-// The graph kernels are instantiated for keys of one to four words (every k <= 128) and for the word counts of the
-// reference's long-read cases (src/Assemble.cpp:42-49): 16, 32, 63, 94 words = k in 481..512, 993..1024, 1985..2016, 2977..3001.
-static int graph_width_unsupported(p3_ctx* c) {
-  return fail(c, P3_EUNSUPPORTED_K, "the de Bruijn stage is built for k <= 128 and for keys of 16, 32, 63 or 94 words "
-                                    "(k = 501, 1001, 2001, 3001 and their neighbours), k=%u", c->k);
+// The graph kernels are instantiated for keys of one to four words (every k <= 128, the key in registers) and for the word
+// counts of the reference's long-read cases (src/Assemble.cpp:42-49): 16, 32, 63, 94 words = k = 501, 1001, 2001, 3001.  A
+// key of any other width above four words runs in the smallest of those that holds it, its upper words zero (DbgParams::nw).
+static int graph_instance(u32 k) {
+  const int nw = nw_of(k);
+  return nw <= 4 ? nw : nw <= 16 ? 16 : nw <= 32 ? 32 : nw <= 63 ? 63 : 94;
 }
 
 extern "C" {
@@ -283,7 +288,7 @@ int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
   int rc;
-  switch (nw_of(c->k)) {
+  switch (graph_instance(c->k)) {
     case 1: rc = mr_build_graph_t<1>(c, cm); break;
     case 2: rc = mr_build_graph_t<2>(c, cm); break;
     case 3: rc = mr_build_graph_t<3>(c, cm); break;
@@ -291,8 +296,7 @@ int p3_mr_build_graph(p3_ctx* c, p3_comm* cm) {
     case 16: rc = mr_build_graph_t<16>(c, cm); break;
     case 32: rc = mr_build_graph_t<32>(c, cm); break;
     case 63: rc = mr_build_graph_t<63>(c, cm); break;
-    case 94: rc = mr_build_graph_t<94>(c, cm); break;
-    default: rc = graph_width_unsupported(c); break;
+    default: rc = mr_build_graph_t<94>(c, cm); break;
   }
   if (rc) xc_abort(cm);
   return rc;
@@ -303,7 +307,7 @@ int p3_build_graph(p3_ctx* c) {
   if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph before p3_make_bloom");
   if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
   HIPCHK(c, hipSetDevice(c->device));
-  switch (nw_of(c->k)) {
+  switch (graph_instance(c->k)) {
     case 1: return build_graph_t<1>(c);
     case 2: return build_graph_t<2>(c);
     case 3: return build_graph_t<3>(c);
@@ -311,8 +315,7 @@ int p3_build_graph(p3_ctx* c) {
     case 16: return build_graph_t<16>(c);
     case 32: return build_graph_t<32>(c);
     case 63: return build_graph_t<63>(c);
-    case 94: return build_graph_t<94>(c);
-    default: return graph_width_unsupported(c);
+    default: return build_graph_t<94>(c);
   }
 }
 

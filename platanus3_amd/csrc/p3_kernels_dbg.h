@@ -54,7 +54,9 @@ struct DbgParams {
   u32 k, H;
   ModM mm;
   u64 mask_top;   // mask of the top key word
-  u32 top_bits;   // 2k - 64 (NW - 1)
+  u32 top_bits;   // 2k - 64 (nw - 1)
+  u32 nw;         // words of the key, <= NW: the wide instances (NW = 16, 32, 63, 94) also serve narrower keys, whose
+                  // words nw .. NW-1 are zero throughout
 };
 
 // ---- key arithmetic ---------------------------------------------------------------------------------------------
@@ -101,10 +103,19 @@ __device__ __forceinline__ DKey<NW> key_rc(const DKey<NW>& a, const DbgParams& p
   for (int t = 0; t < NW; t++) r[t] = ~rev2bit64(a.w[NW - 1 - t]);
   const u32 sh = 64 - p.top_bits;  // 0..62
   DKey<NW> o;
+  if constexpr (NW <= 4) {
 #pragma unroll
-  for (int t = 0; t < NW; t++) {
-    const u64 up = (t + 1 < NW) ? r[t + 1] : 0;
-    o.w[t] = sh ? ((r[t] >> sh) | (up << (64 - sh))) : r[t];
+    for (int t = 0; t < NW; t++) {
+      const u64 up = (t + 1 < NW) ? r[t + 1] : 0;
+      o.w[t] = sh ? ((r[t] >> sh) | (up << (64 - sh))) : r[t];
+    }
+  } else {
+    // (a key of nw < NW words: the unused bits are NW - nw whole words more)
+    const u32 ws = (u32)NW - p.nw;
+    for (u32 t = 0; t < (u32)NW; t++) {
+      const u64 lo = (t + ws < (u32)NW) ? r[t + ws] : 0, up = (t + ws + 1 < (u32)NW) ? r[t + ws + 1] : 0;
+      o.w[t] = sh ? ((lo >> sh) | (up << (64 - sh))) : lo;
+    }
   }
   return o;
 }
@@ -123,7 +134,12 @@ __device__ __forceinline__ DKey<NW> key_left(const DKey<NW>& a, const DbgParams&
   DKey<NW> o;
 #pragma unroll
   for (int t = 0; t < NW - 1; t++) o.w[t] = (a.w[t] >> 2) | (a.w[t + 1] << 62);
-  o.w[NW - 1] = (a.w[NW - 1] >> 2) | ((u64)b << (p.top_bits - 2));
+  if constexpr (NW <= 4) {
+    o.w[NW - 1] = (a.w[NW - 1] >> 2) | ((u64)b << (p.top_bits - 2));
+  } else {
+    o.w[NW - 1] = a.w[NW - 1] >> 2;
+    o.w[p.nw - 1] |= (u64)b << (p.top_bits - 2);
+  }
   return o;
 }
 
@@ -133,7 +149,12 @@ __device__ __forceinline__ DKey<NW> key_right(const DKey<NW>& a, const DbgParams
 #pragma unroll
   for (int t = NW - 1; t > 0; t--) o.w[t] = (a.w[t] << 2) | (a.w[t - 1] >> 62);
   o.w[0] = (a.w[0] << 2) | b;
-  o.w[NW - 1] &= p.mask_top;
+  if constexpr (NW <= 4) {
+    o.w[NW - 1] &= p.mask_top;
+  } else {
+    o.w[p.nw - 1] &= p.mask_top;
+    for (u32 t = p.nw; t < (u32)NW; t++) o.w[t] = 0;  // (what a full top word shifted out)
+  }
   return o;
 }
 
@@ -253,15 +274,16 @@ __device__ __forceinline__ bool node_insert(const DbgTab& t, const DKey<NW>& c, 
 // ctr[0] = next-frontier cursor, ctr[1] = nodes inserted so far, ctr[2] = overflow flag (table too full / frontier full)
 template <int NW>
 static __global__ void __launch_bounds__(256) k_dbg_expand(const u64* __restrict__ fin, const uint8_t* __restrict__ fin_valid,
-                                                    u64 n_in, u64* __restrict__ fout, u64 fout_cap, DbgTab t,
+                                                    u64 n_in, u32 in_words, u64* __restrict__ fout, u64 fout_cap, DbgTab t,
                                                     const u32* __restrict__ bloom, DbgParams p, u64 node_limit,
                                                     u64* __restrict__ ctr) {
   const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_in) return;
   if (fin_valid && !fin_valid[i]) return;
   DKey<NW> key, c;
+  // (in_words per input key: NW for a frontier, the key's own word count for the seeds of a narrower key)
 #pragma unroll
-  for (int j = 0; j < NW; j++) key.w[j] = fin[i * NW + j];
+  for (int j = 0; j < NW; j++) key.w[j] = (u32)j < in_words ? fin[i * in_words + j] : 0;
   u64 slot;
   key_canon<NW>(key, p, c);
   if (!node_insert<NW>(t, c, slot)) {
@@ -414,13 +436,14 @@ static __global__ void __launch_bounds__(256) k_dbg_walk(DbgTab t, DbgParams p, 
 
 // junction keys by id (for the export / GFA writer)
 template <int NW>
-static __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u64* __restrict__ jkeys) {
+static __global__ void __launch_bounds__(256) k_dbg_gather(DbgTab t, u32 out_words, u64* __restrict__ jkeys) {
   const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (s > t.cap_mask) return;
   if (!(t.info[s] & DBG_JUNCTION)) return;
   const u64 id = t.nid[s];
 #pragma unroll
-  for (int j = 0; j < NW; j++) jkeys[id * NW + j] = tab_word(t, j, s);
+  for (int j = 0; j < NW; j++)
+    if ((u32)j < out_words) jkeys[id * out_words + j] = tab_word(t, j, s);  // (the key's own words, as every export)
 }
 
 // ---- k_dbg_coverage ------------------------------------------------------------------------------------------------
@@ -504,12 +527,12 @@ static __global__ void __launch_bounds__(256) k_dbg_coverage(const u64* __restri
         lk.rcw = rcw;
         lk.b0 = 2 * ((w << 5) + j);
         lk.s = 2 * p.k;
-        lk.nw = NW;
+        lk.nw = p.nw;
         lk.top_bits = p.top_bits;
         DKey<NW> f, r;
-        for (int q = 0; q < NW; q++) {
-          f.w[q] = lk.fwd((u32)q);
-          r.w[q] = lk.rc((u32)q);
+        for (u32 q = 0; q < (u32)NW; q++) {
+          f.w[q] = q < p.nw ? lk.fwd(q) : 0;
+          r.w[q] = q < p.nw ? lk.rc(q) : 0;
         }
         dbg_cover_window<NW>(f, r, (w << 5) + j, endm, bases, n_bases, t, p, jcov, jtcov);
       }

@@ -12,8 +12,8 @@
 // Assemble<B> of the shim instead (same outputs; seconds of host time for the STL containers); PLATANUS3_GPUS=N shards the
 // run over N GPUs of the node (AssembleSharded: one thread and one RCCL rank per GPU, same GFA).
 //
-// What differs from the reference binary, on purpose: every k in [21,128] is dispatched (its switch has only 21, 25,
-// 63 and 101 in that range) besides its 501, 1001, 2001, 3001; a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
+// What differs from the reference binary, on purpose: every k in [21,3001] is dispatched (its switch has only 21, 25,
+// 63, 101, 501, 1001, 2001 and 3001 in that range); a run the device path cannot take -- k outside that range, a Bloom vector so dense that the
 // graph closure explodes, no GPU -- ends with a message on stderr and exit status 3 rather than a silent "finish".
 #include <cstdlib>
 
@@ -42,7 +42,7 @@ struct Run {
     const int n_gpus = gpus && *gpus ? std::atoi(gpus) : 0;
     const int status = n_gpus > 0 ? AssembleSharded(reads, opt, log, n_gpus)
                        : (mat && *mat && *mat != '0') ? Assemble_k(reads, opt, log) : AssembleResident(reads, opt, log);
-    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..128, 501, 1001, 2001, 3001)\n";
+    if (status != 0) std::cerr << "platanus3: k=" << opt.kmer_length << " is not dispatched (supported: 21..3001)\n";
     log.WriteLog("finish");
     return status == 0 ? 0 : 3;
   }

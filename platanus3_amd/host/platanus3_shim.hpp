@@ -12,8 +12,7 @@
 // the classes are re-declared with the reference's member names and filled from the flat results of the ABI.
 //
 // Differences a maintainer should know:
-//   * k in [21,128] (one to four key words; the reference's k = 101 included) for the whole Assemble sequence, k up to the
-//     reference's 3001 for CountShortKmer + MakeBF (the de Bruijn stage stops at four words); unsupported k throws (the reference's
+//   * k in [21,3001] (one to 94 key words; the reference's k = 101, 501, 1001, 2001, 3001 included); unsupported k throws (the reference's
 //     Assemble_k silently returns 1, src/Assemble.cpp:51-52);
 //   * materialising the STL containers (17.7 M unordered_map inserts at config #2) costs seconds of host
 //     time -- callers that can consume flat arrays should use the C ABI directly;
@@ -599,15 +598,10 @@ int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
 // Same steps, same log lines, same output file as Assemble<B> above, but nothing is copied back to the host between
 // the stages: the count table, the Bloom vector, the seeds and the graph stay in HBM from p3_load_reads to
 // p3_write_gfa (the command line has no use for KmerCount / BF::m_bits / the three graph maps -- filling them is
-// 9 of the 10 s of a 1 M-read run).  k: AssembleTakes (21..128 and the reference's 501, 1001, 2001, 3001); other k return 1
+// 9 of the 10 s of a 1 M-read run).  k: AssembleTakes (21..3001); other k return 1
 // like Assemble_k.
-// the k the whole sequence (graph stage included) takes: 21..128, and the key widths of the reference's long-read cases --
-// 16, 32, 63 or 94 words: k = 501, 1001, 2001, 3001 and their neighbours (p3_build_graph)
-inline bool AssembleTakes(int k) {
-  if (k >= 21 && k <= 128) return true;
-  const int nw = (2 * k + 63) / 64;
-  return k <= 3001 && (nw == 16 || nw == 32 || nw == 63 || nw == 94);
-}
+// the k the whole sequence (graph stage included) takes: every k from 21 to the reference's widest case, 3001
+inline bool AssembleTakes(int k) { return k >= 21 && k <= 3001; }
 
 inline int AssembleResident(ReadFile& input_reads, Options& options, Logging& logging) {
   if (!AssembleTakes(options.kmer_length)) return 1;
@@ -716,7 +710,7 @@ inline int AssembleSharded(ReadFile& input_reads, Options& options, Logging& log
 
 // Every one- and two-word k (21..64) is dispatched, and the reference's own k = 101, 501, 1001, 2001, 3001 -- the
 // reference's switch (src/Assemble.cpp:31-53) has 21, 25, 63 and those five in the supported range; like there, any other
-// k returns 1 without doing anything.  (AssembleResident takes every k in 21..128 as well: it needs no std::bitset instance.)
+// k returns 1 without doing anything.  (AssembleResident takes every k in 21..3001: it needs no std::bitset instance.)
 inline int Assemble_k(ReadFile& input_reads, Options& options, Logging& logging) {
   switch (options.kmer_length) {
 #define P3SHIM_CASE(K) \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """De Bruijn goldens for the reference's long-read key widths -- k = 501, 1001, 2001, 3001 (src/Assemble.cpp:42-49: keys of
-16, 32, 63 and 94 words) -- from the REAL reference, `-t 1`: Assemble<std::bitset<2k>> (src/Assemble.cpp:6-28) -> GFA in
+16, 32, 63 and 94 words) -- and for widths in between (k = 129, 160, 600, 1500, 2500) from the REAL reference, `-t 1`: Assemble<std::bitset<2k>> (src/Assemble.cpp:6-28) -> GFA in
 ID-free canonical form + the JointInfo::coverage lines, exactly as make_golden_dbg_wide.py does for 65 <= k <= 128.
 ACGT-only inputs.  Output: tests/golden/dbgl_cases.json, dbgl_<name>.canon.gz, dbgl_<name>_reads.npz.  Build container only."""
 import gzip
@@ -25,9 +25,12 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def main():
-    cases = []
+    path = os.path.join(OUT, "dbgl_cases.json")
+    cases = json.load(open(path)) if os.path.exists(path) else []   # (the reference takes minutes per case: new ones only)
 
     def add(name, reads, k, m, H, timeout=1200):
+        if any(c["name"] == name for c in cases):
+            return
         b, off = _flat(reads)
         gfa, joints = ref_run(b, off, k, m, H, timeout)
         nodes, edges = canonical(gfa)
@@ -57,6 +60,14 @@ def main():
     b, off = synth.reads(seed=93, total_reads=300, read_len=1500, sub_rate_ppm=1500)
     add("dense300_k501", (b, off), 501, 1 << 19, 3)
     add("dense300_k1001", (b, off), 1001, 1 << 19, 3)
+    # widths between the reference's own: they run in the next wider instance of the graph kernels, upper key words zero
+    b, off = synth.reads(seed=94, total_reads=400, read_len=600, sub_rate_ppm=2000)
+    add("mid400_k129", (b, off), 129, 1 << 19, 3)
+    add("mid400_k160", (b, off), 160, 1 << 22, 10)
+    b, off = synth.reads(seed=95, total_reads=60, read_len=4000, sub_rate_ppm=400)
+    add("mid60_k600", (b, off), 600, 1 << 22, 10)
+    add("mid60_k1500", (b, off), 1500, 1 << 19, 3, timeout=2400)
+    add("mid60_k2500", (b, off), 2500, 1 << 22, 10, timeout=2400)
     with open(os.path.join(OUT, "dbgl_cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
 

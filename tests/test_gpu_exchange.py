@@ -194,7 +194,7 @@ def test_run_pass_in_groups(oracle, procs, v, k, gate):
 
 @pytest.mark.parametrize("case_name,procs,v", [("synth2000_k31", 1, 4), ("synth3000_k51", 2, 2), ("long40_k63", 1, 2),
                                                 ("wide:synth1500_k101", 1, 4), ("wide:dense3000_k80", 2, 2),
-                                                ("long:dense300_k501", 1, 2), ("long:long40_k3001", 2, 2)])
+                                                ("long:dense300_k501", 1, 2), ("long:long40_k3001", 2, 2), ("long:mid400_k129", 1, 4)])
 def test_sharded_graph_equals_reference_gfa(tmp_path, case_name, procs, v):
     """p3_mr_run_pass + p3_mr_build_graph over procs x v ranks (threads on this one GPU): rank 0's GFA against the REAL
     reference's for the union of the reads (canonical form), JointInfo::coverage included -- keys of one to four words and of

@@ -155,7 +155,7 @@ def test_command_line_end_to_end(tmp_path_factory, tmp_path, name, materialise):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("materialise", [0, 1])
-@pytest.mark.parametrize("name", ["synth1500_k101", "long40_k127", "dbgl:long120_k501", "dbgl:long40_k3001"])
+@pytest.mark.parametrize("name", ["synth1500_k101", "long40_k127", "dbgl:long120_k501", "dbgl:long40_k3001", "dbgl:mid400_k160"])
 def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
     """platanus3 -k 101, -k 501, -k 3001 -- cases of the reference's own switch (src/Assemble.cpp:40-49) -- and -k 127: keys
     of four, sixteen and ninety-four words through the command line, GFA against the real reference's
@@ -167,7 +167,7 @@ def test_command_line_wide_keys(tmp_path_factory, tmp_path, name, materialise):
     from test_oracle_dbg import canon_lines
     prefix = "dbgl" if name.startswith("dbgl:") else "dbgw"
     name = name.split(":")[-1]
-    if materialise and name == "long40_k127":
+    if materialise and name in ("long40_k127", "mid400_k160"):
         pytest.skip("Assemble_k dispatches k = 101, 501, 1001, 2001, 3001 of the wide keys")
     case = [c for c in json.load(open(os.path.join(GOLDEN, prefix + "_cases.json"))) if c["name"] == name][0]
     exe = _compile(tmp_path_factory, "platanus3_main.cpp", "platanus3")
