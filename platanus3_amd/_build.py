@@ -48,7 +48,8 @@ def build_lib(force=False, verbose=False):
     for src in srcs:
         obj = os.path.splitext(src)[0] + ".o"
         if src.endswith(".hip"):
-            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            # (-Wno-pass-failed: the 63- and 94-word instances of the graph kernels keep some `#pragma unroll` loops rolled)
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
                    "-I" + INCLUDE, "-I" + CSRC, "-c", "-o", obj, src]
         else:  # plain C (the synthetic-read generator)
             cmd = ["gcc", "-O3", "-fPIC", "-I" + INCLUDE, "-c", "-o", obj, src]
