@@ -29,16 +29,22 @@ typedef unsigned __int128 u128;
 
 namespace {
 
-// Keys beyond two words (65 <= k <= 128): four 64-bit words, word 0 least significant, with the handful of operators the
-// restatement below uses.  The whole restatement is a template over the key type (u128 for k <= 64, U256 beyond).
-struct U256 {
-  uint64_t w[4];
-  U256() : w{0, 0, 0, 0} {}
-  U256(uint64_t v) : w{v, 0, 0, 0} {}  // NOLINT (implicit on purpose: small constants)
-  friend U256 operator<<(const U256& a, int n) {
-    U256 o;
+// Keys beyond two words: N 64-bit words, word 0 least significant, with the handful of operators the restatement below
+// uses.  The whole restatement is a template over the key type: u128 for k <= 64, UW<4> up to k = 128, and UW<16>, <32>,
+// <63>, <94> for the widths of the reference's long-read cases k = 501, 1001, 2001, 3001 (src/Assemble.cpp:42-49) -- a
+// key of fewer words lives in the next wider type (the mask of 2k bits keeps its upper words zero).
+template <int N>
+struct UW {
+  uint64_t w[N];
+  UW() { std::memset(w, 0, sizeof w); }
+  UW(uint64_t v) {  // NOLINT (implicit on purpose: small constants)
+    std::memset(w, 0, sizeof w);
+    w[0] = v;
+  }
+  friend UW operator<<(const UW& a, int n) {
+    UW o;
     const int ws = n >> 6, bs = n & 63;
-    for (int t = 3; t >= 0; t--) {
+    for (int t = N - 1; t >= 0; t--) {
       uint64_t v = 0;
       if (t - ws >= 0) v = a.w[t - ws] << bs;
       if (bs && t - ws - 1 >= 0) v |= a.w[t - ws - 1] >> (64 - bs);
@@ -46,62 +52,74 @@ struct U256 {
     }
     return o;
   }
-  friend U256 operator>>(const U256& a, int n) {
-    U256 o;
+  friend UW operator>>(const UW& a, int n) {
+    UW o;
     const int ws = n >> 6, bs = n & 63;
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < N; t++) {
       uint64_t v = 0;
-      if (t + ws < 4) v = a.w[t + ws] >> bs;
-      if (bs && t + ws + 1 < 4) v |= a.w[t + ws + 1] << (64 - bs);
+      if (t + ws < N) v = a.w[t + ws] >> bs;
+      if (bs && t + ws + 1 < N) v |= a.w[t + ws + 1] << (64 - bs);
       o.w[t] = v;
     }
     return o;
   }
-  friend U256 operator|(const U256& a, const U256& b) {
-    U256 o;
-    for (int t = 0; t < 4; t++) o.w[t] = a.w[t] | b.w[t];
+  friend UW operator|(const UW& a, const UW& b) {
+    UW o;
+    for (int t = 0; t < N; t++) o.w[t] = a.w[t] | b.w[t];
     return o;
   }
-  friend U256 operator&(const U256& a, const U256& b) {
-    U256 o;
-    for (int t = 0; t < 4; t++) o.w[t] = a.w[t] & b.w[t];
+  friend UW operator&(const UW& a, const UW& b) {
+    UW o;
+    for (int t = 0; t < N; t++) o.w[t] = a.w[t] & b.w[t];
     return o;
   }
-  friend bool operator==(const U256& a, const U256& b) { return std::memcmp(a.w, b.w, 32) == 0; }
-  friend bool operator<(const U256& a, const U256& b) {
-    for (int t = 3; t >= 0; t--)
+  friend bool operator==(const UW& a, const UW& b) { return std::memcmp(a.w, b.w, sizeof a.w) == 0; }
+  friend bool operator<(const UW& a, const UW& b) {
+    for (int t = N - 1; t >= 0; t--)
       if (a.w[t] != b.w[t]) return a.w[t] < b.w[t];
     return false;
   }
-  friend bool operator<=(const U256& a, const U256& b) { return !(b < a); }
+  friend bool operator<=(const UW& a, const UW& b) { return !(b < a); }
 };
+typedef UW<4> U256;
+constexpr int MAXW = 96;  // words of the widest key + slack (k = 3001 takes 94)
 
 inline uint64_t low64(const u128& v) { return (uint64_t)v; }
-inline uint64_t low64(const U256& v) { return v.w[0]; }
-inline void to_words(const u128& v, uint64_t* w) {
+template <int N>
+inline uint64_t low64(const UW<N>& v) { return v.w[0]; }
+inline void to_words(const u128& v, uint64_t* w) {  // (w: MAXW words)
+  std::memset(w, 0, 8 * MAXW);
   w[0] = (uint64_t)v;
   w[1] = (uint64_t)(v >> 64);
-  w[2] = w[3] = 0;
 }
-inline void to_words(const U256& v, uint64_t* w) { std::memcpy(w, v.w, 32); }
+template <int N>
+inline void to_words(const UW<N>& v, uint64_t* w) {
+  std::memset(w, 0, 8 * MAXW);
+  std::memcpy(w, v.w, sizeof v.w);
+}
 inline void from_words(const uint64_t* w, int nw, u128& v) {
   v = w[0];
   if (nw == 2) v |= (u128)w[1] << 64;
 }
-inline void from_words(const uint64_t* w, int nw, U256& v) {
-  v = U256();
+template <int N>
+inline void from_words(const uint64_t* w, int nw, UW<N>& v) {
+  v = UW<N>();
   for (int t = 0; t < nw; t++) v.w[t] = w[t];
 }
 template <typename K>
-inline K mask_of(int k);
+struct MaskOf {
+  static K get(int k) {
+    K m;
+    for (int b = 0; b < 2 * k; b++) m.w[b >> 6] |= 1ULL << (b & 63);
+    return m;
+  }
+};
 template <>
-inline u128 mask_of<u128>(int k) { return (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
-template <>
-inline U256 mask_of<U256>(int k) {
-  U256 m;
-  for (int b = 0; b < 2 * k; b++) m.w[b >> 6] |= 1ULL << (b & 63);
-  return m;
-}
+struct MaskOf<u128> {
+  static u128 get(int k) { return (2 * k == 128) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
+};
+template <typename K>
+inline K mask_of(int k) { return MaskOf<K>::get(k); }
 
 struct HKey {
   size_t operator()(const u128& v) const {
@@ -112,9 +130,10 @@ struct HKey {
     a ^= a >> 32;
     return (size_t)a;
   }
-  size_t operator()(const U256& v) const {
+  template <int N>
+  size_t operator()(const UW<N>& v) const {
     uint64_t a = v.w[0];
-    for (int t = 1; t < 4; t++) {
+    for (int t = 1; t < N; t++) {
       a ^= v.w[t] * 0x9E3779B97F4A7C15ULL;
       a ^= a >> 29;
       a *= 0xBF58476D1CE4E5B9ULL;
@@ -143,7 +162,7 @@ struct Ctx {
   }
   bool recorded(K x) const {  // IsRecorded, src/DeBruijnGraph.cpp:317-323
     K c = canon(x);
-    uint64_t w[4];
+    uint64_t w[MAXW];
     to_words(c, w);
     uint8_t out;
     p3o_bloom_query(bloom, m, H, w, 1, k, &out);
@@ -412,12 +431,18 @@ static int dbg_impl(const char* bases, const uint64_t* offsets, uint64_t n_reads
                     const uint64_t* bloom_words, uint64_t m, int H, const uint64_t* seed_keys, uint64_t n_seeds,
                     char** out_text, uint64_t* out_len, uint64_t* n_junctions, uint64_t* n_joints, uint64_t* n_straights,
                     std::string* joints_out) {
-  if (k < 21 || k > 128) return 2;
-  if (k <= 64)
-    return dbg_impl_t<u128>(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len,
-                            n_junctions, n_joints, n_straights, joints_out);
-  return dbg_impl_t<U256>(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len,
-                          n_junctions, n_joints, n_straights, joints_out);
+  if (k < 21 || k > 3001) return 2;
+#define P3O_DBG_AS(K)                                                                                                      \
+  return dbg_impl_t<K>(bases, offsets, n_reads, min_len, k, bloom_words, m, H, seed_keys, n_seeds, out_text, out_len, \
+                       n_junctions, n_joints, n_straights, joints_out)
+  const int nw = (2 * k + 63) / 64;
+  if (nw <= 2) P3O_DBG_AS(u128);
+  if (nw <= 4) P3O_DBG_AS(U256);
+  if (nw <= 16) P3O_DBG_AS(UW<16>);
+  if (nw <= 32) P3O_DBG_AS(UW<32>);
+  if (nw <= 63) P3O_DBG_AS(UW<63>);
+  P3O_DBG_AS(UW<94>);
+#undef P3O_DBG_AS
 }
 
 extern "C" {

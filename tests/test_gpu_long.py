@@ -170,3 +170,29 @@ def test_sharded_pass_with_long_keys(oracle):
     for words, _ in res:
         assert np.array_equal(words, ewords)
     assert sorted(set(s for _, sd in res for s in sd)) == eseeds
+
+
+@pytest.mark.parametrize("k,n,L,m,H", [(200, 300, 900, 1 << 19, 3), (333, 200, 1500, 1 << 20, 4)])
+def test_long_graph_vs_oracle(oracle, tmp_path, k, n, L, m, H):
+    """widths without a golden (7 and 11 key words in the 16-word instance), dense vectors: the device graph against the
+    oracle's restatement (itself pinned on the reference's goldens up to k = 1001, tests/test_oracle_long.py)"""
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    b, off = synth.reads(seed=190 + k, total_reads=n, read_len=L, sub_rate_ppm=2500)
+    ctx = capi.Context(0)
+    try:
+        ctx.load_reads(b, off, min_len=k)
+        ctx.run_pass(k, m, H)
+        st = ctx.build_graph()
+        path = os.path.join(str(tmp_path), "g.gfa")
+        ctx.write_gfa(path)
+        got = canon_lines(*canonical(open(path).read()))
+        joints = ctx.joint_coverage()
+    finally:
+        ctx.close()
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    gfa, ost = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
+    assert st["n_junctions"] == ost["junctions"] and st["n_straights"] == ost["straights"]
+    assert got == canon_lines(*canonical(gfa))
+    assert joints == oracle.dbg_joints((b, off), words, m, H, seeds, k)

@@ -75,3 +75,33 @@ def test_live_reference_random_reads(oracle, reflib):
         assert np.array_equal(keys, ref["keys"]) and np.array_equal(counts, ref["counts"])
         words, seeds, _, _ = oracle.make_bf((bases, offs), keys, counts, k, m, H)
         assert np.array_equal(words, ref["bloom"]) and seeds == ref["seeds"], (trial, k)
+
+
+# ---- the oracle's de Bruijn restatement beyond four key words --------------------------------------------------------------
+def _dbgl_cases():
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dbgl_cases.json")))
+    # (the restatement reverse-complements base by base over whole words: O(k^2 / 32) per neighbour -- the cases of the
+    #  widest keys take a minute and more each on the CPU and are the device tier's alone)
+    return [c for c in cases if c["k"] <= 600 or c["name"] == "long120_k1001"]
+
+
+@pytest.mark.parametrize("case", _dbgl_cases(), ids=lambda c: c["name"])
+def test_oracle_long_graph_matches_reference(oracle, case):
+    """p3_oracle_dbg.cpp (a template over the key type: UW<16>, UW<32> ... beyond four words, narrower keys in the next wider
+    type) against the REAL reference's GFA and JointInfo::coverage for k = 129 .. 1001 (tests/golden/make_golden_dbg_long.py)"""
+    import gzip
+    from gfa_canon import canonical
+    from test_oracle_dbg import canon_lines
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "dbgl_%s_reads.npz" % case["name"]))
+    b, off = z["bases"], z["offsets"]
+    k, m, H = case["k"], case["m"], case["H"]
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    gfa, st = oracle.dbg_gfa((b, off), words, m, H, seeds, k)
+    assert st["junctions"] == case["n_junctions"] and st["straights"] == case["n_straights"]
+    ls = canon_lines(*canonical(gfa))
+    with gzip.open(os.path.join(os.path.dirname(__file__), "golden", "dbgl_%s.canon.gz" % case["name"]), "rt") as f:
+        assert ls == f.read().split("\n")
+    joints = oracle.dbg_joints((b, off), words, m, H, seeds, k)
+    jl = ["%s\t%d" % (a, c) for a, c in joints]
+    assert len(joints) == case["joints"]["n"] and hashlib.sha256("\n".join(jl).encode()).hexdigest() == case["joints"]["sha256"]
