@@ -171,6 +171,10 @@ typedef struct {
   uint64_t n_nodes, n_junctions, n_joints, n_straights, straight_bases, n_edges, levels;
 } p3_graph_stats;
 int p3_build_graph(p3_ctx* ctx);
+/* MakeDBG(seedkmer, ...) over a seed set the CALLER hands over (src/DeBruijnGraph.cpp:93-105 traverses from the set it
+ * is given, which a caller may have filtered after MakeBF): n_seeds forward-strand keys of nw words each, any order,
+ * duplicates allowed; everything else as p3_build_graph (resident Bloom vector and reads). */
+int p3_build_graph_from(p3_ctx* ctx, const uint64_t* seed_keys, uint64_t n_seeds);
 int p3_get_graph_stats(p3_ctx* ctx, p3_graph_stats* out);
 int p3_export_junctions(p3_ctx* ctx, uint64_t* keys, int32_t* coverage, int32_t* left_cov, int32_t* right_cov,
                         uint64_t cap, uint64_t* n);

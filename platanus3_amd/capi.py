@@ -94,6 +94,7 @@ def load(build=False):
     L.p3_bloom_query.argtypes = [vp, vp, u64, vp]
     L.p3_run_pass.argtypes = [vp, u32, u64, u32]
     L.p3_build_graph.argtypes = [vp]
+    L.p3_build_graph_from.argtypes = [vp, vp, C.c_uint64]
     L.p3_get_graph_stats.argtypes = [vp, C.POINTER(GraphStats)]
     L.p3_export_junctions.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]
@@ -252,6 +253,13 @@ class Context:
     # ---- G3-G6 ---------------------------------------------------------------------------------------
     def build_graph(self):
         self._chk(self.L.p3_build_graph(self.h))
+        return self.graph_stats()
+
+    def build_graph_from(self, seed_keys):
+        """MakeDBG over a seed set of the caller's (forward-strand keys, nw words each) instead of the resident one."""
+        keys = np.ascontiguousarray(seed_keys, dtype=np.uint64).reshape(-1)
+        n = keys.size // nwords(self.k)
+        self._chk(self.L.p3_build_graph_from(self.h, keys.ctypes.data if n else None, n))
         return self.graph_stats()
 
     def graph_stats(self):

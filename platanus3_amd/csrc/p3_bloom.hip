@@ -822,6 +822,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
       rc = nw_of(k) == 1 ? do_bloom_t<1>(c, k, m_bits, H) : do_bloom_t<2>(c, k, m_bits, H);
     } while (0);
     c->spec = false;
+    c->last_pass_replayed = rc == P3_OK;
     if (rc == P3_OK) {
       float ms = 0;
       if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->tm.ms_pack = ms;
@@ -833,6 +834,7 @@ int p3_run_pass(p3_ctx* c, uint32_t k, uint64_t m_bits, uint32_t H) {
     if (rc != P3_ERETRY_INTERNAL) return rc;
     (void)hipStreamSynchronize(c->stream);  // fall through to the careful path
   }
+  c->last_pass_replayed = false;
   if ((rc = p3_count_short(c))) return rc;
   if ((rc = p3_make_bloom(c, k, m_bits, H))) return rc;
   float ms = 0;

@@ -233,7 +233,7 @@ int p3_destroy(p3_ctx* c) {
                     &c->g_jcov, &c->g_runs, &c->g_seqoff, &c->g_seq, &c->g_edges, &c->g_jkeys, &c->apart, &c->seg_off2,
                     &c->ghist2, &c->part8c, &c->sroff_d, &c->klpart, &c->zero8, &c->dall, &c->cellcnt, &c->caps, &c->unk_flag,
                     &c->seed_part, &c->seed_hist, &c->seed_set, &c->seed_ucount, &c->seed_flag, &c->g_jtcov, &c->xc_buf,
-                    &c->xg_buf, &c->g_k2, &c->g_k3, &c->g_kx, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3]};
+                    &c->xg_buf, &c->g_k2, &c->g_k3, &c->g_kx, &c->segoff_cache[0], &c->segoff_cache[1], &c->segoff_cache[2], &c->segoff_cache[3], &c->redo};
   for (DevBuf* b : bufs) release(*b);
   free_outgrown(c);
   for (auto& ev : c->ev)
@@ -316,6 +316,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
     // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
     forget_learnt(c, false);
+  } else if (n == "count_slots") {
+    if (value < 0 || value > 1) return fail(c, P3_EBADARG, "count_slots must be 0 (4-byte quotient slots where they apply) or 1 (8-byte slots only)");
+    c->countq_opt = (int)value;
   } else if (n == "run_records") {
     if (value < 0 || value > 2) return fail(c, P3_EBADARG, "run_records must be 0 (auto), 1 (never) or 2 (wherever they apply)");
     c->sk_opt = (int)value;
@@ -354,6 +357,17 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "est_fallbacks") *value = (int64_t)c->ad.fallbacks;
   else if (n == "kmer_groups") *value = (int64_t)c->kgroups;
   else if (n == "est_level") *value = c->ad.est_ok ? (int64_t)c->ad.est_boost : 3;  // 0..2 = boost level in use, 3 = exact
+  else if (n == "pass_replayed") *value = c->last_pass_replayed ? 1 : 0;
+  else if (n == "quotient_tables") *value = c->q_tables;
+  else if (n == "quotient_redone") {  // tables the quotient-slot count left to k_part_count (heavy keys, crowded tables)
+    *value = 0;
+    if (c->q_tables && c->redo.p) {
+      std::vector<u32> h(c->q_tables);
+      if (hipMemcpy(h.data(), c->redo.p, (size_t)c->q_tables * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(c, P3_EHIP, "reading the redo flags failed");
+      for (u32 v : h) *value += v ? 1 : 0;
+    }
+  }
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);

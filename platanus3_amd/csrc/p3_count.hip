@@ -14,6 +14,7 @@ namespace p3i {
 
 int do_count_direct(p3_ctx* c) {
   int rc;
+  c->q_tables = 0;
   // direct table: capacity = pow2 >= 1.5 * (upper bound on distinct keys = number of bases)
   u64 want = c->n_bases + c->n_bases / 2 + 1024;
   u64 cap = 1024;
@@ -292,6 +293,7 @@ int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
+  c->q_tables = 0;
   if (c->n_ranks > 1 && c->part_pos && c->ad.est_ok && c->sizing_opt != 1 && c->n_ranks <= 8) {
     // position records: owner-side split through the stager with estimated capacities (k_split; no histogram pass).
     // From an 8-way sub-bucket split on, the owned buckets are processed in 2^xg groups with xg more split bits
@@ -359,11 +361,26 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
                  k2_mode(c));
     } else {
+      // one reader per bucket on 4-byte quotient slots (p3_kernels_countq.h): tables of twice the keys, so one split
+      // bit less; what such a table cannot hold (a key with >= 1024 instances, a crowded table) is flagged and
+      // counted by the launch behind it, which returns at once for everything else
+      const bool q = c->countq_opt != 1 && c->n_ranks == 1 && xbits == 0 && sbits >= 1 && !k2_mode(c) && ts_log2 == P3_TS_LOG2_MAX;
+      if (q) {
+        const u32 nq = rows << (sbits - 1);
+        c->q_tables = nq;
+        if ((rc = ensure(c, c->redo, (size_t)nq * 4))) return rc;
+        LAUNCH_LDS(c, "k_part_countq", k_part_countq, nq, 1024, lds, (const u64*)kpart, (const u32*)kseg, (const u32*)khist,
+                   c->rank * rows, 0u, sbits - 1, (u64*)c->ckeys.p, (u32*)c->ccounts.p, st, (u64*)c->tpos.p,
+                   (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32*)c->redo.p);
+        c->k2ext_h[1] = (u64)(uintptr_t)c->redo.p;
+        HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
+      }
       LAUNCH_K2(false, nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
                  (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
                  k2_mode(c));
+      if (q) HIPCHK(c, hipMemsetAsync(st + 33, 0, 8, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
@@ -415,6 +432,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
 // accumulate over the groups.
 int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
+  c->q_tables = 0;
   const bool mr = c->n_ranks > 1, chunked = !mr && c->chunks > 1;
   const u32 n_src = mr ? c->n_ranks : (chunked ? c->chunks : 1u);
   u32 lg = 0;  // split bits that come from the owner's share of the buckets (multi-rank only)

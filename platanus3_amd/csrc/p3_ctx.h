@@ -30,6 +30,7 @@
 #include "p3_kernels_part.h"
 #include "p3_kernels_bloom.h"
 #include "p3_kernels_retgate.h"
+#include "p3_kernels_countq.h"
 #include "p3_kernels_sk.h"
 #include "p3_kernels_seedset.h"
 #include "p3_kernels_wide.h"
@@ -163,6 +164,8 @@ struct p3_ctx {
   bool part_pos = false;  // the current partition carries positions (8-byte records)
   bool part_est = false;  // ... and was laid out with estimated segment capacities
   DevBuf part8, tpos, tsrc, singles, sing_cursor, ns_recv, ns_part;
+  DevBuf redo;  // k_part_countq: tables left to k_part_count (p3_kernels_countq.h)
+  u32 q_tables = 0;  // tables the last count stage ran on quotient slots (0 = it did not)
   u64 sing_count[P3_MAX_RANKS] = {0};
   bool s_ready = false;
   // de Bruijn stage
@@ -173,6 +176,7 @@ struct p3_ctx {
   std::vector<u64> g_seqoff_host;
   // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
   bool spec = false;
+  bool last_pass_replayed = false;  // the last p3_run_pass was the single-synchronisation replay (info "pass_replayed")
   u32 hint_sbits = 1, hint_ksbits = 0, hint_k = 0, hint_H = 0;
   u64 hint_nsing = 0;
   u32 pass_hint_k = 0;
@@ -194,6 +198,7 @@ struct p3_ctx {
   int sk_dbg = 0;            // timing experiments (results are wrong when non-zero)
   int sk_waves_opt = 16;     // waves per workgroup of the run-record consumers (4..16)
   int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
+  int countq_opt = 0;        // 0 = count stage on 4-byte quotient slots where they apply (p3_kernels_countq.h), 1 = never
   DevBuf unk_flag;           // set by k_pack when a base is not A/C/G/T
 
   // the seed SET on the device (p3_kernels_seedset.h): 2^seedset_bbits sorted runs of distinct keys, ocap slots each

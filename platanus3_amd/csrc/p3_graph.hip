@@ -174,11 +174,17 @@ u64 graph_node_estimate(const p3_ctx* c) {
   return est;
 }
 
+// d_seeds == nullptr: the resident seeds of the preceding p3_make_bloom (one candidate per read + validity bytes);
+// otherwise n_seeds keys the caller handed over (p3_build_graph_from), all valid
 template <int NW>
-int build_graph_t(p3_ctx* c) {
+int build_graph_t(p3_ctx* c, const u64* d_seeds = nullptr, u64 n_seeds = 0) {
   int rc;
   c->graphed = false;
-  if ((rc = graph_structure<NW>(c, (const u64*)c->seeds.p, (const uint8_t*)c->seed_valid.p, c->n_reads, graph_node_estimate(c)))) return rc;
+  u64 est = graph_node_estimate(c);
+  if (d_seeds && est < n_seeds) est = n_seeds;
+  if ((rc = d_seeds ? graph_structure<NW>(c, d_seeds, nullptr, n_seeds, est)
+                    : graph_structure<NW>(c, (const u64*)c->seeds.p, (const uint8_t*)c->seed_valid.p, c->n_reads, est)))
+    return rc;
   if ((rc = graph_coverage<NW>(c))) return rc;
   return graph_links<NW>(c);
 }
@@ -317,6 +323,33 @@ int p3_build_graph(p3_ctx* c) {
     case 63: return build_graph_t<63>(c);
     default: return build_graph_t<94>(c);
   }
+}
+
+int p3_build_graph_from(p3_ctx* c, const uint64_t* seed_keys, uint64_t n_seeds) {
+  if (!c) return P3_EBADARG;
+  if (!c->bloomed) return fail(c, P3_ESTATE, "p3_build_graph_from before p3_make_bloom");
+  if (!c->d_bases) return fail(c, P3_ESTATE, "reads are gone");
+  if (n_seeds && !seed_keys) return fail(c, P3_EBADARG, "null seed keys");
+  HIPCHK(c, hipSetDevice(c->device));
+  const u64 nw = (u64)nw_of(c->k);
+  DevBuf d;
+  int rc;
+  if ((rc = ensure(c, d, (n_seeds + 1) * 8 * nw))) return rc;
+  if (n_seeds) HIPCHK(c, hipMemcpyAsync(d.p, seed_keys, n_seeds * 8 * nw, hipMemcpyHostToDevice, c->stream));
+  const u64* ds = (const u64*)d.p;
+  switch (graph_instance(c->k)) {
+    case 1: rc = build_graph_t<1>(c, ds, n_seeds); break;
+    case 2: rc = build_graph_t<2>(c, ds, n_seeds); break;
+    case 3: rc = build_graph_t<3>(c, ds, n_seeds); break;
+    case 4: rc = build_graph_t<4>(c, ds, n_seeds); break;
+    case 16: rc = build_graph_t<16>(c, ds, n_seeds); break;
+    case 32: rc = build_graph_t<32>(c, ds, n_seeds); break;
+    case 63: rc = build_graph_t<63>(c, ds, n_seeds); break;
+    default: rc = build_graph_t<94>(c, ds, n_seeds); break;
+  }
+  (void)hipStreamSynchronize(c->stream);
+  release(d);
+  return rc;
 }
 
 int p3_get_graph_stats(p3_ctx* c, p3_graph_stats* out) {

@@ -398,23 +398,22 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_kmer_scatter(const u
       REC rec[RW];
       u32 bkt[RW];
       u32 pend = 0;
+      // every window's record is computed unconditionally (a lane without reads rolls garbage that `pend` masks out):
+      // no branch per window
 #pragma unroll
       for (int i = 0; i < RW; i++) {
-        bkt[i] = 0;
-        if (pbits & 1u) {
-          u64 lo, hi;
-          kr.canonical(lo, hi);
-          if constexpr (NW == 1) rec[i] = lo;
-          else {
-            rec[i].lo = lo;
-            rec[i].hi = hi;
-          }
-          bkt[i] = (u32)(khash<NW>(lo, hi) >> (64 - P3_PBITS));
-          pend |= 1u << i;
+        u64 lo, hi;
+        kr.canonical(lo, hi);
+        if constexpr (NW == 1) rec[i] = lo;
+        else {
+          rec[i].lo = lo;
+          rec[i].hi = hi;
         }
-        pbits >>= 1;
-        if (active) kr.roll();
+        bkt[i] = (kfold<NW>(lo, hi) * 0x9E3779B1u) >> (32 - P3_PBITS);
+        kr.roll();
       }
+      pend = pbits & ((1u << RW) - 1u);
+      pbits >>= RW;
       stage_round<REC, RW>(stg, part, est, rec, bkt, pend, carry);
     }
   }

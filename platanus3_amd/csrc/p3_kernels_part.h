@@ -310,6 +310,16 @@ static __global__ void __launch_bounds__(1024) k_part_count(const typename std::
                                                      u32* __restrict__ singles,
                                                      u64* __restrict__ sing_cursor, u32 dbg, u32 mode) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
+  if constexpr (POS) {
+    // launched behind k_part_countq (p3_kernels_countq.h): gstats[33] = its table of flags, one per PAIR of this
+    // kernel's sub-buckets; only the flagged ones are counted here
+    const u32* redo = reinterpret_cast<const u32*>(gstats[33]);
+    if (redo) {
+      const u32 nsub0 = 1u << sbits;
+      const u32 grp0 = blockIdx.x / (8u * nsub0), rr0 = blockIdx.x % (8u * nsub0);
+      if (!redo[((grp0 * 8u + (rr0 & 7u)) * nsub0 + (rr0 >> 3)) >> 1]) return;
+    }
+  }
   // Two rarely used inputs ride in arrays the kernel has anyway (more kernel arguments cost the hot loop registers):
   // gstats[30] = entries that out_keys / out_counts hold; sing_cursor[P3_MAX_RANKS + s] = where source s's list of
   // single-instance positions starts in `singles`.

@@ -58,20 +58,19 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_part_scatter_pos(con
       }
     }
     pend = 0;
+    // every window's record is computed unconditionally (a lane without words rolls garbage that `pend` masks out):
+    // no branch per window
+    const u32 pos0 = ((u32)w << 5) + (u32)(round * RW);
 #pragma unroll
     for (int i = 0; i < RW; i++) {
-      rec[i] = 0;
-      bkt[i] = 0;
-      if ((vbits >> (round * RW + i)) & 1u) {
-        u64 lo, hi;
-        kr.canonical(lo, hi);
-        const u64 g = mix42(lo);
-        rec[i] = (((w << 5) + (u64)(round * RW + i)) << 32) | (g & 0xffffffffULL);
-        bkt[i] = (u32)(g >> 32);
-        pend |= 1u << i;
-      }
-      if (active) kr.roll();
+      u64 lo, hi;
+      kr.canonical(lo, hi);
+      const u64 g = mix42(lo);
+      rec[i] = ((u64)(pos0 + (u32)i) << 32) | (u32)g;
+      bkt[i] = (u32)(g >> 32);
+      kr.roll();
     }
+    pend = (vbits >> (round * RW)) & ((1u << RW) - 1u);
     round++;
     return true;
   });

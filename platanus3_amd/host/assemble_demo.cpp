@@ -1,11 +1,12 @@
 // assemble_demo.cpp -- the reference's Assemble<B> call order (src/Assemble.cpp:9-12) through the shim.
 //
-//   assemble_demo <reads.fasta> <k> <m> <H> <out_prefix> [graph]
+//   assemble_demo <reads.fasta> <k> <m> <H> <out_prefix> [graph]      (P3_DEMO_SEEDS=<file>: MakeDBG from that seed set)
 //
 // Writes <out_prefix>.counts (key<TAB>count, sorted), <out_prefix>.bloom (uint64 words) and
 // <out_prefix>.seeds (one per line, std::set order).  FASTA reading here is a 10-line stand-in for
 // src/Load.cpp:51-75 (host I/O is out of scope of the accelerated path).
 #include <algorithm>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -35,6 +36,13 @@ int run(ReadFile& input_reads, int k, uint64_t m, int H, const std::string& out)
   if (!g_with_graph) return 0;
   // the rest of Assemble<B> (src/Assemble.cpp:19-26): graph, coverage, GFA (written to ./de_bruijn_graph.gfa)
   DeBruijnGraph<B> first_dbg(k, bf, logging);
+  if (const char* sf = std::getenv("P3_DEMO_SEEDS")) {  // a caller that edits the seed set between MakeBF and MakeDBG
+    std::ifstream fsd(sf);
+    std::string line;
+    seedkmer.clear();
+    while (std::getline(fsd, line))
+      if (!line.empty()) seedkmer.insert(line);
+  }
   first_dbg.MakeDBG(seedkmer, m, (uint8_t)H, 8);
   first_dbg.CountNodeCoverage(input_reads.reads);
   first_dbg.PrintGraph();

@@ -86,6 +86,13 @@ struct Session {
   uint32_t loaded_min_len = 0;
   bool counted = false;
   uint64_t kc_size = 0, kc_print = 0;  // the KmerCount CountShortKmer materialised (MakeBF checks it was not edited)
+  uint64_t seeds_size = ~0ull, seeds_print = 0;  // the seed set MakeBF materialised (MakeDBG checks it was not edited)
+  static uint64_t seeds_fingerprint(const std::set<std::string>& s) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ s.size();
+    for (const std::string& q : s)
+      for (unsigned char ch : q) h = (h ^ ch) * 0x100000001b3ULL;
+    return h;
+  }
   static Session& get() {
     static Session s;
     return s;
@@ -433,6 +440,8 @@ BF<LARGE_BITSET> MakeBF(ReadSet& RS, KmerCount& KC, uint64_t filtersize, uint8_t
     }
     seed_kmer->insert(sd);
   }
+  p3shim::Session::get().seeds_size = seed_kmer->size();
+  p3shim::Session::get().seeds_print = p3shim::Session::seeds_fingerprint(*seed_kmer);
   return bf;
 }
 
@@ -475,13 +484,30 @@ class DeBruijnGraph {
   DeBruijnGraph(int k, BF<LARGE_BITSET>& first_bloom_filter, Logging& input_logging)
       : kmer_length(k), bitset_length(2 * k), all_kmers(&first_bloom_filter), logging(&input_logging) {}
 
-  // MakeDBG (:93-155).  The seed set, filter size and hash count live in the device context of the MakeBF call that
-  // produced `first_bloom_filter`; the arguments are accepted for signature compatibility (the reference ignores the
-  // last three itself).
+  // MakeDBG (:93-155) traverses from the seed set it is HANDED (:96-105).  The set MakeBF produced is resident on the
+  // device; a set that differs from it (a caller that filtered or extended the seeds between the two calls) is
+  // uploaded instead (p3_build_graph_from).  Filter size, hash count and thread count are accepted for signature
+  // compatibility (the reference ignores the first two itself, :93-155).
   void MakeDBG(std::set<std::string>& seedkmer, uint64_t, uint8_t, int) {
-    (void)seedkmer;
-    p3_ctx* ctx = p3shim::Session::get().context();
-    p3shim::check(ctx, p3_build_graph(ctx), "p3_build_graph");
+    p3shim::Session& ses = p3shim::Session::get();
+    p3_ctx* ctx = ses.context();
+    if (seedkmer.size() == ses.seeds_size && p3shim::Session::seeds_fingerprint(seedkmer) == ses.seeds_print) {
+      p3shim::check(ctx, p3_build_graph(ctx), "p3_build_graph");
+    } else {
+      const int snw = (bitset_length + 63) / 64;
+      std::vector<uint64_t> sk(seedkmer.size() * (size_t)snw + 1, 0);
+      size_t si = 0;
+      for (const std::string& sd : seedkmer) {  // GetFirstKmerForward (src/BitCalc.cpp:7-19): unknown characters are A
+        for (int b = 0; b < kmer_length && b < (int)sd.size(); b++) {
+          const char ch = sd[(size_t)b];
+          const uint64_t code = ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 0;
+          const int bit = 2 * (kmer_length - 1 - b);
+          sk[si * (size_t)snw + (size_t)(bit >> 6)] |= code << (bit & 63);
+        }
+        si++;
+      }
+      p3shim::check(ctx, p3_build_graph_from(ctx, sk.data(), seedkmer.size()), "p3_build_graph_from");
+    }
     p3_graph_stats g;
     p3shim::check(ctx, p3_get_graph_stats(ctx, &g), "p3_get_graph_stats");
     const int nw = (bitset_length + 63) / 64;

@@ -65,3 +65,36 @@ def test_dense_filter_is_refused_not_hung(ctx):
     with pytest.raises(capi.P3Error) as e:
         ctx.build_graph()
     assert e.value.code == 3
+
+
+def test_graph_from_a_seed_set_of_the_callers(ctx, oracle, tmp_path):
+    """MakeDBG traverses from the seed set it is HANDED (src/DeBruijnGraph.cpp:93-105).  Reads of two unrelated genomes,
+    one Bloom vector over both, seeds of the first genome only: p3_build_graph_from yields that genome's component
+    alone -- the oracle's graph for the same set -- and fewer nodes than the graph from the resident seeds."""
+    k = 31
+    b1, o1 = synth.reads(seed=301, total_reads=3000, read_len=150)
+    b2, o2 = synth.reads(seed=302, total_reads=3000, read_len=150)
+    b = np.concatenate([b1, b2])
+    off = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    ctx.load_reads(b, off, min_len=k)
+    ctx.run_pass(k, m, H)
+    full = ctx.build_graph()
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds_all, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    k1, c1 = oracle.count_short((b1, o1), min_len=k)
+    _, seeds1, _, _ = oracle.make_bf((b1, o1), k1, c1, k, m, H)
+    assert 0 < len(seeds1) < len(seeds_all) and set(seeds1) <= set(seeds_all)
+    nw = capi.nwords(k)
+    sk = np.zeros((len(seeds1), nw), np.uint64)
+    for i, s in enumerate(seeds1):
+        sk[i] = oracle.encode_fwd(s, k)
+    st = ctx.build_graph_from(sk)
+    assert st["n_nodes"] < full["n_nodes"]
+    path = os.path.join(str(tmp_path), "sub.gfa")
+    ctx.write_gfa(path)
+    want, ost = oracle.dbg_gfa((b, off), words, m, H, seeds1, k)
+    assert st["n_junctions"] == ost["junctions"] and st["n_straights"] == ost["straights"]
+    gn, ge = canonical(open(path).read())
+    wn, we = canonical(want)
+    assert gn == wn and ge == we

@@ -5,6 +5,7 @@
   * 2 / 4 / 8 ranks on one GPU through the callback communicator: N contexts driven by threads, the callbacks copy
     between the ranks' DEVICE buffers -- the same p3_mr_run_pass code path as over RCCL, minus the wire
 Results must equal the single-rank oracle on the union of the reads, bit for bit."""
+import os
 import threading
 
 import numpy as np
@@ -423,3 +424,41 @@ def test_cpp_host_drives_the_sharded_pass(tmp_path):
         assert ctx.bloom_stats()["n_passing"] == passing
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("world,k,reshard,graph", [(2, 31, 0, 1), (4, 31, 1, 0), (4, 45, 0, 0)])
+def test_run_pass_in_separate_processes(oracle, tmp_path, world, k, reshard, graph):
+    """p3_mr_run_pass with every rank in its OWN process (python -m torch.distributed.run, one GPU shared by all):
+    the collectives of a callbacks communicator go through gloo with host staging (tests/mp_mr_worker.py).  Checks
+    what the thread-driven tests cannot: the launch contract, processes that each own a HIP context on the device,
+    ids and results crossing process boundaries, and the teardown order.  Union of the ranks' tables, every rank's
+    merged vector and the union of the seeds equal the oracle's single-process results; with `graph`, rank 0's sharded
+    de Bruijn graph equals the oracle's."""
+    import subprocess
+    import sys
+    import socket
+    from gfa_canon import canonical
+    n_reads, seed = 16000, 64
+    m, H = oracle.estimate_bloom(n_reads * 150, k)
+    with socket.socket() as s:  # a free port for the rendezvous
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "mp_mr_worker.py"), str(tmp_path), str(n_reads), str(k), str(m), str(H),
+           str(seed), str(reshard), str(graph)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-4000:]
+    b, o = synth.reads(seed=seed, total_reads=n_reads, read_len=150)
+    res = []
+    for rk in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rk))
+        res.append((z["keys"], z["counts"], z["bloom"], [capi.decode_key(x, k) for x in z["seeds"]]))
+    _check_union(oracle, b, o, k, m, H, res)
+    if graph:
+        ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+        words, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
+        want, _ = oracle.dbg_gfa((b, o), words, m, H, eseeds, k)
+        got = open(os.path.join(str(tmp_path), "graph.gfa")).read()
+        assert canonical(got) == canonical(want)

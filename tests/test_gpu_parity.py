@@ -345,6 +345,22 @@ def test_config2_full_size_against_reference_checksums(ctx):
         for i in range(k):
             rc |= (np.uint64(3) - ((samp >> np.uint64(2 * i)) & np.uint64(3))) << np.uint64(2 * (k - 1 - i))
         assert ctx.bloom_query(np.minimum(samp, rc)).all()
+    # The path bench.py TIMES is p3_run_pass: a careful first pass over new reads, then the single-synchronisation
+    # replay with the splits and sizes it remembered.  Both must give the digests the reference gave.
+    run = g["runs"][0]
+    ctx.set_option("drop_hints", 1)
+    for want_replay in (0, 1, 1):
+        ctx.run_pass(k, run["m"], run["H"])
+        assert ctx.get_info("pass_replayed") == want_replay
+        keys, counts = ctx.export_counts()
+        assert sha(keys) == g["keys_sha256"] and sha(counts) == g["counts_sha256"]
+        assert sha(ctx.export_bloom()) == run["bloom_sha256"]
+        seeds = ctx.export_seeds()
+        sk = seeds[:, 0]
+        chars = np.empty((sk.size, k), np.uint8)
+        for i in range(k):
+            chars[:, i] = lut[((sk >> np.uint64(2 * (k - 1 - i))) & np.uint64(3)).astype(np.int64)]
+        assert seeds.shape[0] == run["n_seeds"] and sha(chars) == run["seeds_sha256"]
 
 
 @pytest.mark.parametrize("world,k,gate,agg", [(2, 31, 2, 1), (4, 31, 2, 1), (4, 41, 1, 1), (8, 25, 2, 1), (4, 31, 2, 0), (4, 27, 2, 2), (8, 31, 2, 3),
@@ -1058,3 +1074,47 @@ def test_count_overflow_is_reported_not_truncated(oracle):
         t.join()
     e0 = errors[0]
     assert isinstance(e0, capi.P3Error) and e0.code == 6, errors  # P3_ECOUNT_OVERFLOW
+
+
+def test_quotient_slot_count_leaves_heavy_keys_to_the_wide_kernel(oracle):
+    """The count stage's 4-byte quotient slots (p3_kernels_countq.h) hold 10-bit counters: a 21-mer with 1024 instances
+    or more wraps one, the table's sum check sees it, the table is flagged and k_part_count -- launched right behind,
+    idle for every other table -- counts it.  Reads with a poly-A stretch (one key with ~40,000 instances), (AC)n and
+    (ACG)n repeats among ordinary reads: same table, vector and seeds as the oracle and as a run on 8-byte slots only;
+    ordinary reads alone flag nothing."""
+    rng = np.random.default_rng(11)
+    b0, o0 = synth.reads(seed=23, total_reads=60000, read_len=150)
+    reads = [b0[int(o0[i]):int(o0[i + 1])].copy() for i in range(60000)]
+    for i in range(0, 60000, 30):  # 2000 reads: a 40-base stretch of a repeat unit in the middle
+        u = (b"A", b"AC", b"ACG")[(i // 30) % 3]
+        reads[i][50:90] = np.frombuffer((u * 40)[:40], dtype=np.uint8)
+    b = np.concatenate(reads)
+    o = np.concatenate([[0], np.cumsum([r.size for r in reads])]).astype(np.uint64)
+    k = 31
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    c = capi.Context(0)
+    try:
+        run_and_compare(c, oracle, (b, o), k, m, H)
+        assert c.get_info("quotient_tables") > 0 and c.get_info("quotient_redone") >= 1
+        assert c.count_stats()["max_count"] >= 1024
+        keys, counts = c.export_counts()
+        words = c.export_bloom()
+        c.run_pass(k, m, H)  # the replayed pass takes the same route
+        k3, c3 = c.export_counts()
+        assert np.array_equal(keys, k3) and np.array_equal(counts, c3) and np.array_equal(words, c.export_bloom())
+    finally:
+        c.close()
+    c = capi.Context(0)
+    try:
+        c.set_option("count_slots", 1)  # 8-byte slots only
+        c.load_reads(b, o, k)
+        c.run_pass(k, m, H)
+        assert c.get_info("quotient_tables") == 0
+        k2, c2 = c.export_counts()
+        assert np.array_equal(keys, k2) and np.array_equal(counts, c2) and np.array_equal(words, c.export_bloom())
+        c.load_reads(b0, o0, k)  # ordinary reads: nothing to redo
+        c.set_option("count_slots", 0)
+        c.run_pass(k, m, H)
+        assert c.get_info("quotient_tables") > 0 and c.get_info("quotient_redone") == 0
+    finally:
+        c.close()

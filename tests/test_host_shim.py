@@ -157,3 +157,38 @@ def test_shim_full_assemble_gfa_wide_keys(tmp_path, prefix, name):
     with gzip.open(os.path.join(GOLDEN, "%s_%s.canon.gz" % (prefix, name)), "rt") as f:
         assert ls == f.read().split("\n")
     assert hashlib.sha256("\n".join(ls).encode()).hexdigest() == case["sha256"]
+
+
+@pytest.mark.gpu
+def test_shim_makedbg_honours_the_seed_set_it_is_handed(tmp_path, oracle):
+    """DeBruijnGraph::MakeDBG(seedkmer, ...) traverses from the set it is GIVEN (src/DeBruijnGraph.cpp:93-105).  A caller
+    that replaces the set MakeBF returned by the seeds of one of two unrelated genomes gets that genome's component --
+    the oracle's graph for that set -- not the graph of the resident seeds."""
+    import platanus3_amd.synth as synth
+    from gfa_canon import canonical
+    k = 31
+    b1, o1 = synth.reads(seed=301, total_reads=2000, read_len=150)
+    b2, o2 = synth.reads(seed=302, total_reads=2000, read_len=150)
+    b = np.concatenate([b1, b2])
+    off = np.concatenate([o1, o2[1:] + o1[-1]]).astype(np.uint64)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    keys, counts = oracle.count_short((b, off), min_len=k)
+    words, seeds_all, _, _ = oracle.make_bf((b, off), keys, counts, k, m, H)
+    k1, c1 = oracle.count_short((b1, o1), min_len=k)
+    _, seeds1, _, _ = oracle.make_bf((b1, o1), k1, c1, k, m, H)
+    exe = _compile(tmp_path)
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for i in range(off.size - 1):
+            f.write(">r%d\n%s\n" % (i, b[int(off[i]):int(off[i + 1])].tobytes().decode()))
+    sf = os.path.join(str(tmp_path), "seeds1.txt")
+    with open(sf, "w") as f:
+        f.write("\n".join(seeds1) + "\n")
+    out = os.path.join(str(tmp_path), "out")
+    env = dict(os.environ, P3_DEMO_SEEDS=sf)
+    subprocess.check_call([exe, fa, str(k), str(m), str(H), out, "graph"], cwd=str(tmp_path), timeout=120, env=env)
+    got = open(os.path.join(str(tmp_path), "de_bruijn_graph.gfa")).read()
+    want, _ = oracle.dbg_gfa((b, off), words, m, H, seeds1, k)
+    full, _ = oracle.dbg_gfa((b, off), words, m, H, seeds_all, k)
+    assert canonical(got) == canonical(want)
+    assert canonical(got) != canonical(full)
