@@ -502,101 +502,95 @@ int p3_comm_destroy(p3_comm* cm) {
 
 
 // ---- reads grouped by genomic neighbourhood (p3_kernels_shard.h) ---------------------------------------------------------
-// The context's reads, copied into `grouped` so that the reads of group g = (shard key mod W) are contiguous (original
-// order inside a group); lens = their lengths in the new order, cnt_* / off_* = reads and bases per group.  One-time work:
-// the bookkeeping is done on the host from two small per-read arrays.
-static int group_reads_by_key(p3_ctx* c, u32 W, DevBuf& grouped, std::vector<u32>& lens, u64* cnt_reads, u64* cnt_bases,
-                              u64* off_reads, u64* off_bases) {
+// The context's reads, copied into `grouped` so that the reads of group g (shard key mod W; outsized keys and reads without
+// a 21-mer round robin) are contiguous; d_rel = for every read IN THE NEW ORDER its offset relative to its group's segment;
+// cnt_* / off_* = reads and bases per group.  All on the device: keys, per-block counts, scan, places, copy; the host
+// reads back 2 W totals.
+static int group_reads_by_key(p3_ctx* c, u32 W, DevBuf& grouped, DevBuf& d_rel, u64* cnt_reads, u64* cnt_bases, u64* off_reads,
+                              u64* off_bases) {
   int rc;
   const u64 n = c->n_reads;
-  DevBuf d_owner, d_len, d_pos;  // (d_owner holds the 64-bit shard keys)
+  const u64 n_blocks = (n + P3_SHARD_BLOCK - 1) / P3_SHARD_BLOCK;
+  DevBuf d_key, d_len, d_pos, d_hcnt, d_blk, d_tot;
   auto done = [&](int code) {
-    release(d_owner);
-    release(d_len);
-    release(d_pos);
+    DevBuf* tmp[] = {&d_key, &d_len, &d_pos, &d_hcnt, &d_blk, &d_tot};
+    for (DevBuf* b : tmp) release(*b);
     return code;
   };
-  if ((rc = ensure(c, d_owner, (n + 1) * 8)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
+  if ((rc = ensure(c, d_key, (n + 1) * 8)) || (rc = ensure(c, d_len, (n + 1) * 4)) || (rc = ensure(c, d_pos, (n + 1) * 8)) ||
+      (rc = ensure(c, d_rel, (n + 1) * 8)) || (rc = ensure(c, d_hcnt, (size_t)4 << P3_SHARD_HLOG2)) ||
+      (rc = ensure(c, d_blk, (n_blocks + 1) * W * 16)) || (rc = ensure(c, d_tot, (size_t)P3_MAX_RANKS * 16)) ||
       (rc = ensure(c, grouped, c->n_bases + 64)))
     return done(rc);
+  u64* blk_reads = (u64*)d_blk.p;
+  u64* blk_bases = blk_reads + (n_blocks + 1) * W;
+  u64* tot_reads = (u64*)d_tot.p;
+  u64* tot_bases = tot_reads + P3_MAX_RANKS;
+  if (hipMemsetAsync(d_hcnt.p, 0, (size_t)4 << P3_SHARD_HLOG2, c->stream) != hipSuccess ||
+      hipMemsetAsync(d_tot.p, 0, (size_t)P3_MAX_RANKS * 16, c->stream) != hipSuccess)
+    return done(fail(c, P3_EHIP, "re-shard: clearing the counters failed"));
+  // keys shared by an outsized number of reads have no neighbourhood to keep together and would overload one group
+  const u32 heavy = (u32)std::min<u64>(0x7fffffffu, std::max<u64>(256, n / ((u64)W * 64)));
   if (n) {
     hipLaunchKernelGGL(k_shard_keys, dim3(grid_for(n, 256, 1u << 30)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
-                       (u64*)d_owner.p, (u32*)d_len.p);
-    if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "k_shard_keys launch"));
+                       (u64*)d_key.p, (u32*)d_len.p, (u32*)d_hcnt.p);
+    hipLaunchKernelGGL((k_shard_blocks<false>), dim3((unsigned)n_blocks), dim3(P3_SHARD_BLOCK), 0, c->stream, (const u64*)d_key.p,
+                       (const u32*)d_len.p, (const u32*)d_hcnt.p, n, W, heavy, blk_reads, blk_bases, (const u64*)nullptr,
+                       (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+    hipLaunchKernelGGL(k_shard_scan, dim3(W), dim3(1024), 0, c->stream, blk_reads, blk_bases, n_blocks, W, tot_reads, tot_bases);
+    hipLaunchKernelGGL((k_shard_blocks<true>), dim3((unsigned)n_blocks), dim3(P3_SHARD_BLOCK), 0, c->stream, (const u64*)d_key.p,
+                       (const u32*)d_len.p, (const u32*)d_hcnt.p, n, W, heavy, blk_reads, blk_bases, (const u64*)tot_reads,
+                       (const u64*)tot_bases, (u64*)d_pos.p, (u64*)d_rel.p);
+    hipLaunchKernelGGL(k_move_reads, dim3(grid_for(n * 64, 256, 1u << 16)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
+                       (const u64*)d_pos.p, (uint8_t*)grouped.p);
+    if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "re-shard kernels: launch failed"));
   }
-  std::vector<u64> key(n);
-  std::vector<u32> owner(n), len(n);
-  if (n && (hipMemcpyAsync(key.data(), d_owner.p, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(len.data(), d_len.p, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess))
-    return done(fail(c, P3_EHIP, "shard keys copy"));
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, P3_EHIP, "shard keys sync"));
-  {
-    // keys shared by an outsized number of reads (a repeat whose 21-mer happens to hash low): their reads have no
-    // neighbourhood to keep together and would overload one group -- dealt round robin, like the reads without a 21-mer
-    std::vector<u64> sorted(key);
-    std::sort(sorted.begin(), sorted.end());
-    const u64 heavy = std::max<u64>(256, n / ((u64)W * 64));
-    std::vector<u64> heavy_keys;
-    for (u64 i = 0; i < n;) {
-      u64 j = i;
-      while (j < n && sorted[j] == sorted[i]) j++;
-      if (j - i > heavy && sorted[i] != ~0ULL) heavy_keys.push_back(sorted[i]);
-      i = j;
-    }
-    u64 rr = 0;
-    for (u64 i = 0; i < n; i++) {
-      const bool spread = key[i] == ~0ULL || (!heavy_keys.empty() && std::binary_search(heavy_keys.begin(), heavy_keys.end(), key[i]));
-      owner[i] = spread ? (u32)(rr++ % W) : (u32)(key[i] % W);
-    }
-  }
-  for (u32 d = 0; d < W; d++) cnt_reads[d] = cnt_bases[d] = 0;
-  for (u64 i = 0; i < n; i++) {
-    cnt_reads[owner[i]]++;
-    cnt_bases[owner[i]] += len[i];
-  }
+  u64 tot[2 * P3_MAX_RANKS];
+  if (hipMemcpyAsync(tot, d_tot.p, sizeof tot, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    return done(fail(c, P3_EHIP, "re-shard: %s", hipGetErrorString(hipGetLastError())));
   off_reads[0] = off_bases[0] = 0;
   for (u32 d = 0; d < W; d++) {
+    cnt_reads[d] = tot[d];
+    cnt_bases[d] = tot[P3_MAX_RANKS + d];
     off_reads[d + 1] = off_reads[d] + cnt_reads[d];
     off_bases[d + 1] = off_bases[d] + cnt_bases[d];
   }
-  std::vector<u64> pos(n);
-  lens.assign(n, 0);
-  {
-    std::vector<u64> cur_r(off_reads, off_reads + W), cur_b(off_bases, off_bases + W);
-    for (u64 i = 0; i < n; i++) {
-      const u32 d = owner[i];
-      pos[i] = cur_b[d];
-      lens[cur_r[d]++] = len[i];
-      cur_b[d] += len[i];
-    }
-  }
-  if (n) {
-    if (hipMemcpyAsync(d_pos.p, pos.data(), n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
-      return done(fail(c, P3_EHIP, "layout copy"));
-    hipLaunchKernelGGL(k_move_reads, dim3(grid_for(n * 64, 256, 1u << 16)), dim3(256), 0, c->stream, c->d_bases, c->d_offsets, n,
-                       (const u64*)d_pos.p, (uint8_t*)grouped.p);
-    if (hipGetLastError() != hipSuccess) return done(fail(c, P3_EHIP, "k_move_reads launch"));
-  }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(c, P3_EHIP, "move reads"));  // (pos is a host vector)
+  if (off_reads[W] != n || off_bases[W] != c->n_bases) return done(fail(c, P3_EHIP, "re-shard: the groups do not add up"));
   return done(P3_OK);
 }
 
-// the context takes `bases` (n_new reads of the given lengths, back to back) as its reads
-static int install_reads(p3_ctx* c, DevBuf& bases, const std::vector<u32>& lens) {
-  const u64 n_new = lens.size();
-  std::vector<u64> offs(n_new + 1);
-  offs[0] = 0;
-  u64 hw = 0;
-  for (u64 i = 0; i < n_new; i++) {
-    offs[i + 1] = offs[i] + lens[i];
-    if (lens[i] >= c->min_len && lens[i] >= P3_SHORTK) hw += lens[i] - (P3_SHORTK - 1);
-  }
-  DevBuf new_offsets;
+// the context takes `bases` as its reads: n_new reads in W segments (segment s: reads [seg_reads[s], seg_reads[s+1]), bases
+// from seg_bases[s]), d_rel[j] = offset of read j relative to its segment
+static int install_reads(p3_ctx* c, DevBuf& bases, const DevBuf& d_rel, u32 W, const u64* seg_reads, const u64* seg_bases) {
+  const u64 n_new = seg_reads[W], b_new = seg_bases[W];
+  DevBuf new_offsets, d_seg;
   int rc;
-  if ((rc = ensure(c, new_offsets, (n_new + 1) * 8))) return rc;
-  if (hipMemcpy(new_offsets.p, offs.data(), (n_new + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) {
+  if ((rc = ensure(c, new_offsets, (n_new + 1) * 8)) || (rc = ensure(c, d_seg, (size_t)(2 * P3_MAX_RANKS + 4) * 8))) {
     release(new_offsets);
-    return fail(c, P3_EHIP, "offsets copy");
+    return rc;
+  }
+  u64 h[2 * P3_MAX_RANKS + 4] = {0};
+  for (u32 s = 0; s <= W; s++) {
+    h[s] = seg_reads[s];
+    h[P3_MAX_RANKS + 1 + s] = seg_bases[s];
+  }
+  u64* d = (u64*)d_seg.p;  // [0..W] segment reads, [65..65+W] segment bases, [130..131] window sum / monotonic flag
+  u64 out[2] = {0, 0};
+  bool ok = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_rebase_offsets, dim3(grid_for(n_new + 1)), dim3(256), 0, c->stream, (const u64*)d_rel.p, n_new, W,
+                       (const u64*)d, (const u64*)(d + P3_MAX_RANKS + 1), (u64*)new_offsets.p);
+    hipLaunchKernelGGL(k_window_sum, dim3(grid_for(n_new ? n_new : 1)), dim3(256), 0, c->stream, (const u64*)new_offsets.p, n_new,
+                       c->min_len, d + 2 * P3_MAX_RANKS + 2);
+    ok = hipGetLastError() == hipSuccess &&
+         hipMemcpyAsync(out, d + 2 * P3_MAX_RANKS + 2, 16, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  release(d_seg);
+  if (!ok || out[1]) {
+    release(new_offsets);
+    return fail(c, ok ? P3_ECOMM : P3_EHIP, ok ? "re-sharded reads: offsets and bases disagree" : "re-shard: installing the reads failed");
   }
   release(c->owned_bases);
   release(c->owned_offsets);
@@ -606,8 +600,8 @@ static int install_reads(p3_ctx* c, DevBuf& bases, const std::vector<u32>& lens)
   c->d_bases = (const uint8_t*)c->owned_bases.p;
   c->d_offsets = (const u64*)c->owned_offsets.p;
   const u32 min_len = c->min_len;
-  rc = set_reads_common(c, n_new, offs[n_new], min_len);
-  c->host_windows = hw;
+  rc = set_reads_common(c, n_new, b_new, min_len);
+  c->host_windows = out[0];
   return rc;
 }
 
@@ -623,17 +617,17 @@ int p3_group_reads(p3_ctx* c, uint32_t n_groups) {
     while (n_groups < 64 && c->n_words * 32 / n_groups > (1ull << 30)) n_groups <<= 1;
   }
   if (n_groups > P3_MAX_RANKS) return fail(c, P3_EBADARG, "at most %d groups", P3_MAX_RANKS);
-  DevBuf grouped;
-  std::vector<u32> lens;
+  DevBuf grouped, d_rel;
   u64 cr[P3_MAX_RANKS], cb[P3_MAX_RANKS], orr[P3_MAX_RANKS + 1], ob[P3_MAX_RANKS + 1];
-  int rc = group_reads_by_key(c, n_groups, grouped, lens, cr, cb, orr, ob);
-  if (!rc) rc = install_reads(c, grouped, lens);
+  int rc = group_reads_by_key(c, n_groups, grouped, d_rel, cr, cb, orr, ob);
+  if (!rc) rc = install_reads(c, grouped, d_rel, n_groups, orr, ob);
   release(grouped);
+  release(d_rel);
   return rc;
 }
 
 // Deal the reads of a sharded job out once more, by genomic neighbourhood: group by (shard key mod n_ranks), one variable
-// all-to-all of the bases and one of the lengths, install.
+// all-to-all of the bases and one of the segment-relative offsets, install.
 int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
   if (!c || !cm) return P3_EBADARG;
   if (!c->have_reads) return fail(c, P3_ESTATE, "p3_mr_reshard_reads before p3_load_reads");
@@ -641,19 +635,15 @@ int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
   if (W > P3_MAX_RANKS) return fail(c, P3_EBADARG, "too many ranks");
   int rc;
   HIPCHK(c, hipSetDevice(c->device));
-  DevBuf d_send, d_sendlen, d_recvlen, new_bases;
+  DevBuf d_send, d_rel, d_recvrel, new_bases;
   auto bail = [&](int code) {
-    DevBuf* tmp[] = {&d_send, &d_sendlen, &d_recvlen, &new_bases};
+    DevBuf* tmp[] = {&d_send, &d_rel, &d_recvrel, &new_bases};
     for (DevBuf* b : tmp) release(*b);
     if (code && cm->group) cm->group->abort();
     return code;
   };
-  std::vector<u32> sendlen;
   u64 cnt_reads[P3_MAX_RANKS], cnt_bases[P3_MAX_RANKS], off_reads[P3_MAX_RANKS + 1], off_bases[P3_MAX_RANKS + 1];
-  if ((rc = group_reads_by_key(c, W, d_send, sendlen, cnt_reads, cnt_bases, off_reads, off_bases))) return bail(rc);
-  const u64 n = sendlen.size();
-  if ((rc = ensure(c, d_sendlen, (n + 1) * 4))) return bail(rc);
-  if (n && hipMemcpy(d_sendlen.p, sendlen.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(c, P3_EHIP, "lengths copy"));
+  if ((rc = group_reads_by_key(c, W, d_send, d_rel, cnt_reads, cnt_bases, off_reads, off_bases))) return bail(rc);
   // what everybody sends me
   u64 rcnt_reads[P3_MAX_RANKS], rcnt_bases[P3_MAX_RANKS], roff_reads[P3_MAX_RANKS + 1] = {0}, roff_bases[P3_MAX_RANKS + 1] = {0};
   if ((rc = exchange_counts(c, cm, cnt_reads, rcnt_reads)) || (rc = exchange_counts(c, cm, cnt_bases, rcnt_bases))) return bail(rc);
@@ -662,18 +652,11 @@ int p3_mr_reshard_reads(p3_ctx* c, p3_comm* cm) {
     roff_bases[s2 + 1] = roff_bases[s2] + rcnt_bases[s2];
   }
   const u64 n_new = roff_reads[W], b_new = roff_bases[W];
-  if ((rc = ensure(c, new_bases, b_new + 64)) || (rc = ensure(c, d_recvlen, (n_new + 1) * 4))) return bail(rc);
+  if ((rc = ensure(c, new_bases, b_new + 64)) || (rc = ensure(c, d_recvrel, (n_new + 1) * 8))) return bail(rc);
   if ((rc = comm_a2av(cm, d_send.p, off_bases, cnt_bases, new_bases.p, roff_bases, rcnt_bases, 1, c->stream)) ||
-      (rc = comm_a2av(cm, d_sendlen.p, off_reads, cnt_reads, d_recvlen.p, roff_reads, rcnt_reads, 4, c->stream)))
+      (rc = comm_a2av(cm, d_rel.p, off_reads, cnt_reads, d_recvrel.p, roff_reads, rcnt_reads, 8, c->stream)))
     return bail(fail(c, rc, "%s", cm->err.c_str()));
-  std::vector<u32> rlen(n_new);
-  if (n_new && hipMemcpyAsync(rlen.data(), d_recvlen.p, n_new * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-    return bail(fail(c, P3_EHIP, "lengths copy"));
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return bail(fail(c, P3_EHIP, "exchange sync"));
-  u64 total = 0;
-  for (u32 L : rlen) total += L;
-  if (total != b_new) return bail(fail(c, P3_ECOMM, "re-sharded reads: lengths and bases disagree"));
-  rc = install_reads(c, new_bases, rlen);
+  rc = install_reads(c, new_bases, d_recvrel, W, roff_reads, roff_bases);
   return bail(rc);
 }
 
