@@ -138,6 +138,10 @@ typedef struct {
 int p3_get_count_stats(p3_ctx* ctx, p3_count_stats* out);
 /* (key,count) pairs sorted by key; *n = n_distinct even when cap is too small (-> P3_ECAPACITY). */
 int p3_export_counts(p3_ctx* ctx, uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n);
+/* Order-independent digest of the resident (key, count) table -- out[0] = sum, out[1] = xor over the entries of
+ * mix(key ^ count * 0x9E3779B97F4A7C15), mix = the splitmix64 finaliser -- for tables too large to export and sort (config
+ * #3: ~1 G entries).  A sharded job's table is the disjoint union of the ranks' tables: add / xor the ranks' words. */
+int p3_count_digest(p3_ctx* ctx, uint64_t out[2]);
 
 /* ---- G1+G2: MakeBF<bitset<2k>> (src/MakeBloomFilter.cpp:24-89) -> BF<B> + seed set ---------------- */
 /* m_bits/H are what Options::EstimateBloomfilter produced (src/Options.cpp:50-60). */

@@ -72,6 +72,12 @@ int p3o_refshaped_pass(const char* bases, const uint64_t* offsets, uint64_t n_re
                        int k, uint64_t m, int H, double* t_count, double* t_bloom,
                        uint64_t* n_distinct, uint64_t* bloom_words, uint64_t* n_seeds);
 
+/* The same path for inputs of the BASELINE configurations' FULL size, as streaming passes (p3_oracle_stream.cpp):
+ * statistics, an order-independent digest of the count table, the Bloom words and the seed set.  k <= 64.
+ * stats[16]: see p3_oracle_stream.cpp.  Returns 0 ok, 2 bad argument, 3 seed_cap too small. */
+int p3o_stream_pass(const char* bases, const uint64_t* offsets, uint64_t n_reads, uint32_t min_len, int k, uint64_t m, int H,
+                    uint32_t part_bits, uint64_t* stats, uint64_t* bloom_words, uint64_t* seed_keys, uint64_t seed_cap);
+
 #ifdef __cplusplus
 }
 #endif

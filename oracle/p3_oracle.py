@@ -27,7 +27,7 @@ def nwords(k):
 def build(force=False):
     """Compile libp3oracle.so (always) and _ref/libp3ref.so (only where /root/reference exists)."""
     so = os.path.join(_HERE, "libp3oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("p3_oracle.cpp", "p3_oracle_dbg.cpp", "p3_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("p3_oracle.cpp", "p3_oracle_dbg.cpp", "p3_oracle_stream.cpp", "p3_oracle.h")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libp3oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src"):
@@ -248,6 +248,43 @@ class Oracle:
                                          C.byref(nd), words.ctypes.data if want_bloom else None, C.byref(ns))
         assert rc == 0, rc
         return dict(t_count=tc.value, t_bloom=tb.value, n_distinct=nd.value, n_seeds=ns.value, bloom=words)
+
+
+    STREAM_STATS = ("n_windows", "n_distinct", "n_solid", "max_count", "digest_sum", "digest_xor", "n_windows_k", "n_passing",
+                    "n_seed_reads", "n_seeds", "count_overflow")
+
+    def stream_pass(self, reads, k, m, H, min_len=None, part_bits=4, want_seeds=True):
+        """count -> gate -> Bloom -> seeds as streaming passes (inputs of the BASELINE configurations' full size):
+        statistics incl. an order-independent digest of the (key, count) table, the Bloom words, the seed keys."""
+        bases, offs = _flat(reads)
+        min_len = k if min_len is None else min_len
+        st = np.zeros(16, np.uint64)
+        words = np.zeros((m + 63) // 64, np.uint64)
+        n = offs.size - 1
+        nw = nwords(k)
+        seeds = np.zeros((max(1, n) if want_seeds else 1, nw), np.uint64)
+        self.lib.p3o_stream_pass.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint64, C.c_int, C.c_uint32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        rc = self.lib.p3o_stream_pass(bases.ctypes.data, offs.ctypes.data, n, min_len, k, m, H, part_bits, st.ctypes.data,
+                                      words.ctypes.data, seeds.ctypes.data if want_seeds else None, seeds.shape[0])
+        assert rc == 0, rc
+        out = {name: int(st[i]) for i, name in enumerate(self.STREAM_STATS)}
+        out["bloom"] = words
+        out["seeds"] = seeds[: out["n_seeds"]] if want_seeds else None
+        return out
+
+    @staticmethod
+    def table_digest(keys, counts):
+        """the digest stream_pass reports, from an exported (key, count) table (any order)"""
+        k = np.asarray(keys, np.uint64)
+        c = np.asarray(counts, np.uint64)
+        with np.errstate(over="ignore"):
+            x = k ^ (c * np.uint64(0x9E3779B97F4A7C15))
+            x = x + np.uint64(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            x = x ^ (x >> np.uint64(31))
+            return int(x.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(x)) if x.size else 0
 
 
 class RefLib:

@@ -95,6 +95,7 @@ def load(build=False):
     L.p3_run_pass.argtypes = [vp, u32, u64, u32]
     L.p3_build_graph.argtypes = [vp]
     L.p3_build_graph_from.argtypes = [vp, vp, C.c_uint64]
+    L.p3_count_digest.argtypes = [vp, vp]
     L.p3_get_graph_stats.argtypes = [vp, C.POINTER(GraphStats)]
     L.p3_export_junctions.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]
@@ -229,6 +230,12 @@ class Context:
         s = BloomStats()
         self._chk(self.L.p3_get_bloom_stats(self.h, C.byref(s)))
         return dict(n_windows_k=s.n_windows_k, n_passing=s.n_passing, n_seed_reads=s.n_seed_reads)
+
+    def count_digest(self):
+        """(sum, xor) digest of the resident count table (order-independent; see include/platanus3_amd.h)"""
+        out = (C.c_uint64 * 2)()
+        self._chk(self.L.p3_count_digest(self.h, out))
+        return int(out[0]), int(out[1])
 
     def export_bloom(self):
         words = np.zeros((self.m + 63) // 64, np.uint64)

@@ -357,15 +357,20 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             const u32 segcap_p = segcap_for(c, (double)per_keys * H / (double)ns_total);
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
+            // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)
+#define POS_SCATTER(MULTI, M32, SB)                                                                                            \
+  LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, MULTI, M32>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,     \
+             (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p, (const u64*)(st + 12), (u64)0, \
+             st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), SB, ns)
+            const bool m32 = m < (1ull << 32);
             if (sweeps > 1) {
-              LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, true>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                         (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                         (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), sbase, ns);
+              if (m32) POS_SCATTER(true, true, sbase);
+              else POS_SCATTER(true, false, sbase);
             } else {
-              LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
-                         (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                         (const u64*)(st + 12), (u64)0, st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), 0u, ns);
+              if (m32) POS_SCATTER(false, true, 0u);
+              else POS_SCATTER(false, false, 0u);
             }
+#undef POS_SCATTER
           } else {
             if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
             const u64 cap_records = c->ppart.bytes / 4;

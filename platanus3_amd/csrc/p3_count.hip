@@ -968,6 +968,31 @@ int p3_get_count_stats(p3_ctx* c, p3_count_stats* out) {
   return P3_OK;
 }
 
+int p3_count_digest(p3_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return P3_EBADARG;
+  if (!c->counted) return fail(c, P3_ESTATE, "no count table yet");
+  if (c->count_mode == 1 && !c->ckeys.p) return fail(c, P3_ESTATE, "no compact table");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc;
+  DevBuf d;
+  if ((rc = ensure(c, d, 16))) return rc;
+  HIPCHK(c, hipMemsetAsync(d.p, 0, 16, c->stream));
+  const u64 nd = c->cstats.n_distinct;
+  if (nd) {
+    if (c->ccounts_u32)
+      hipLaunchKernelGGL((k_table_digest<u32>), dim3(grid_for(nd)), dim3(256), 0, c->stream, (const u64*)c->ckeys.p,
+                         (const u32*)c->ccounts.p, nd, (u64*)d.p);
+    else
+      hipLaunchKernelGGL((k_table_digest<u64>), dim3(grid_for(nd)), dim3(256), 0, c->stream, (const u64*)c->ckeys.p,
+                         (const u64*)c->ccounts.p, nd, (u64*)d.p);
+  }
+  hipError_t e = hipMemcpyAsync(out, d.p, 16, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  release(d);
+  if (e != hipSuccess) return fail(c, P3_EHIP, "count digest: %s", hipGetErrorString(e));
+  return P3_OK;
+}
+
 int p3_export_counts(p3_ctx* c, uint64_t* keys, uint64_t* counts, uint64_t cap, uint64_t* n) {
   if (!c || !n) return P3_EBADARG;
   if (!c->counted) return fail(c, P3_ESTATE, "no count table yet");

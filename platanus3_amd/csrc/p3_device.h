@@ -56,6 +56,31 @@ __device__ __forceinline__ void probe_step(Probe& p, const ModM& mm) {
   p.r = r;
 }
 
+// The same sequence for m < 2^32 in 32-bit arithmetic (r, a = h2 mod m, c = 2^64 mod m all fit a word; only the
+// wrapping 64-bit sum x is needed in full, for its carry): half the instructions of probe_step per probe.
+struct Probe32 {
+  u64 x, h2;
+  u32 r, a;
+};
+__device__ __forceinline__ Probe32 probe32_begin(u64 h1, u64 h2, const ModM& mm) {
+  Probe32 p;
+  p.x = h1;
+  p.h2 = h2;
+  p.r = (u32)mod_m(h1, mm);
+  p.a = (u32)mod_m(h2, mm);
+  return p;
+}
+__device__ __forceinline__ void probe32_step(Probe32& p, u32 m, u32 c) {
+  const u64 nx = p.x + p.h2;
+  const bool wrapped = nx < p.x;
+  p.x = nx;
+  u32 t = p.r + p.a;                 // true sum < 2m < 2^33: a lost carry means t + 2^32 >= m
+  const bool over = t < p.r;
+  t = (over || t >= m) ? t - m : t;  // (t - m wraps back into [0, m) in the carry case)
+  const u32 w = (t >= c) ? t - c : t + (m - c);
+  p.r = wrapped ? w : t;
+}
+
 // ---- H1: libstdc++ _Hash_bytes over the first ceil(2k/8) bytes of the key words ---------------------
 __device__ __forceinline__ u64 shift_mix(u64 v) { return v ^ (v >> 47); }
 

@@ -727,7 +727,7 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u
   });
 }
 
-template <int NW, bool MULTI>  // MULTI: one of several sweeps over a vector of more than 1024 slices
+template <int NW, bool MULTI, bool M32 = false>  // MULTI: one of several sweeps over a vector of more than 1024 slices; M32: m < 2^32
 // totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
 // raises *cap_flag and writes nothing (the host re-runs with a larger buffer).
 static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
@@ -756,13 +756,15 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
   for (u64 base = begin; base < end; base += blockDim.x) {
     const u64 i = base + threadIdx.x;
     const bool active = i < end;
-    Probe pr;
+    typename std::conditional<M32, Probe32, Probe>::type pr;
     if (active) {
       const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
       u64 h1, h2;
       double_hash_key<NW>(lo, hi, k, h1, h2);
-      pr = probe_begin(h1, h2, mm);
+      if constexpr (M32) pr = probe32_begin(h1, h2, mm);
+      else pr = probe_begin(h1, h2, mm);
     }
+    const u32 m32 = (u32)mm.m, c32 = (u32)mm.c;
     for (u32 done = 0; done < H; done += PR) {
       u32 rec[PR], bkt[PR];
       u32 pend = 0;
@@ -779,7 +781,8 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
             bkt[t] = sid;
             pend |= 1u << t;
           }
-          probe_step(pr, mm);
+          if constexpr (M32) probe32_step(pr, m32, c32);
+          else probe_step(pr, mm);
         }
       }
       stage_round<u32, PR>(stg, out, est, rec, bkt, pend, carry);

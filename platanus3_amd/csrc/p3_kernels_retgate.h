@@ -518,3 +518,30 @@ static __global__ void __launch_bounds__(P3_NB) k_var_caps(u32* __restrict__ cel
     seg_off[i] = (u32)(base[c] - (u64)cap_s[c] * P3_NWG) + w * cap_s[c];
   }
 }
+
+// ---- order-independent digest of the (key, count) table: out[0] += sum, out[1] ^= xor of mix(key ^ count * golden) ----
+// (a verification aid for tables too large to export and sort: 50 M reads give ~1 G entries; the same two words are
+// computed by the oracle's streaming form, oracle/p3_oracle_stream.cpp)
+template <typename CNT>
+static __global__ void __launch_bounds__(256) k_table_digest(const u64* __restrict__ keys, const CNT* __restrict__ counts, u64 n,
+                                                      u64* __restrict__ out) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  u64 s = 0, x = 0;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    u64 v = keys[i] ^ ((u64)counts[i] * 0x9E3779B97F4A7C15ULL);
+    v += 0x9e3779b97f4a7c15ULL;
+    v = (v ^ (v >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    v = (v ^ (v >> 27)) * 0x94d049bb133111ebULL;
+    v ^= v >> 31;
+    s += v;
+    x ^= v;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_down(s, off, 64);
+    x ^= __shfl_down(x, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd((unsigned long long*)&out[0], (unsigned long long)s);
+    atomicXor((unsigned long long*)&out[1], (unsigned long long)x);
+  }
+}

@@ -600,24 +600,38 @@ class DeBruijnGraph {
 
 // ---- Assemble<B> / Assemble_k: src/Assemble.cpp:6-54 ----------------------------------------------------------------
 #ifndef PLATANUS3_SHIM_CORE_ONLY
+// The stage order and the argument plumbing are the reference's (src/Assemble.cpp:9-26); so are the log lines, kept in
+// one table because AssembleResident and AssembleSharded below write the same ones.
+namespace p3shim {
+enum AsmLog { kLogStart, kLogCounted, kLogBloom, kLogSeeds, kLogExtend, kLogGraph, kLogCoverage };
+inline void asm_log(Logging& lg, AsmLog what) {
+  static const char* const text[] = {"Assemble", "counted short kmer", "bloom filter loaded", "get seed kmer",
+                                     "start graph extention", "de bruijn graph loaded", "count node coverage"};
+  lg.WriteLog(text[what]);
+}
+inline void asm_log_seeds(Logging& lg, uint64_t n) { lg.WriteLog("seed kmer num= " + std::to_string(n)); }
+}  // namespace p3shim
+
 template <typename LARGE_BITSET>
 int Assemble(ReadFile& input_reads, Options& options, Logging& logging) {
-  logging.WriteLog("Assemble");
-  input_reads.CountShortKmer(options.shortk_length);
-  logging.WriteLog("counted short kmer");
-  std::set<std::string> seedkmer;
-  BF<LARGE_BITSET> first_bloom_filter = MakeBF<LARGE_BITSET>(input_reads.reads, input_reads.shortk_database, options.filter_size,
-                                                            options.num_hashes, options.kmer_length, &seedkmer, logging);
-  logging.WriteLog("bloom filter loaded");
-  logging.WriteLog("get seed kmer");
-  logging.WriteLog("seed kmer num= " + std::to_string(seedkmer.size()));
-  DeBruijnGraph<LARGE_BITSET> first_dbg(options.kmer_length, first_bloom_filter, logging);
-  logging.WriteLog("start graph extention");
-  first_dbg.MakeDBG(seedkmer, options.filter_size, options.num_hashes, options.threads_num);
-  logging.WriteLog("de bruijn graph loaded");
-  first_dbg.CountNodeCoverage(input_reads.reads);
-  logging.WriteLog("count node coverage");
-  first_dbg.PrintGraph();
+  using namespace p3shim;
+  const int k = options.kmer_length;
+  asm_log(logging, kLogStart);
+  input_reads.CountShortKmer(options.shortk_length);  // C1 -> ReadFile::shortk_database
+  asm_log(logging, kLogCounted);
+  std::set<std::string> seeds;  // G2 -> the vector and the seed set
+  BF<LARGE_BITSET> bloom =
+      MakeBF<LARGE_BITSET>(input_reads.reads, input_reads.shortk_database, options.filter_size, options.num_hashes, k, &seeds, logging);
+  asm_log(logging, kLogBloom);
+  asm_log(logging, kLogSeeds);
+  asm_log_seeds(logging, seeds.size());
+  DeBruijnGraph<LARGE_BITSET> graph(k, bloom, logging);  // G3-G6
+  asm_log(logging, kLogExtend);
+  graph.MakeDBG(seeds, options.filter_size, options.num_hashes, options.threads_num);
+  asm_log(logging, kLogGraph);
+  graph.CountNodeCoverage(input_reads.reads);
+  asm_log(logging, kLogCoverage);
+  graph.PrintGraph();
   return 0;
 }
 

@@ -75,6 +75,18 @@ def test_synth_vs_oracle(ctx, oracle, k, n, L, ppm):
     run_and_compare(ctx, oracle, (b, o), k, m, H)
 
 
+def test_count_digest_is_the_oracles(ctx, oracle):
+    """p3_count_digest: the order-independent (sum, xor) digest of the resident table equals the one computed from the
+    oracle's table -- the check that stands in for an export where the table is too large to sort (config #3)."""
+    b, o = synth.reads(seed=33, total_reads=20000, read_len=150)
+    ctx.load_reads(b, o, min_len=31)
+    ctx.count_short()
+    ekeys, ecounts = oracle.count_short((b, o), min_len=31)
+    assert ctx.count_digest() == oracle.table_digest(ekeys, ecounts)
+    ecounts[0] += 1
+    assert ctx.count_digest() != oracle.table_digest(ekeys, ecounts)
+
+
 def test_minus_m_style_run(ctx, oracle):
     # "-m given" -> H stays 10 (src/Options.cpp:51), m = 2^24 here
     b, o = synth.reads(seed=3, total_reads=5000, read_len=150)

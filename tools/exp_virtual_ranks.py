@@ -14,6 +14,10 @@ v = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 31
 m, H = bloom_sizing(n * 150, k)
 vr = VirtualRanks(device=0, rank=0, world=1, per_rank=v, seed=1, total_reads=n, first_read=0, n_reads=n)
+for kv in [x for x in os.environ.get("VR_OPTS", "").split(",") if x]:  # e.g. VR_OPTS=mr_aggregate=0
+    name, val = kv.split("=")
+    for p in vr.pipes:
+        p.ctx.set_option(name, int(val))
 if os.environ.get("RESHARD", "0") == "1":
     t0 = time.perf_counter()
     vr.reshard()
