@@ -334,9 +334,21 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       // form's scan keeps a bit in hand).  50 M reads on one GPU: two sweeps instead of four, pass 281 -> 266 ms, same vector.
       const u64 pos_limit = 1ull << (c->pos_limit_log2_opt ? c->pos_limit_log2_opt : (est ? 32 : 31));
       auto sweeps_for = [&](u32 sub) { return (u32)((((m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub)) + P3_NB - 1) / P3_NB); };
+      // records the fixed-stride layout of ONE sweep addresses (32-bit record offsets): buckets x workgroups x the
+      // segment capacity -- which carries the boost of the current estimate level.  (Round 3: the rule used to be
+      // n_pos / sweeps + n_pos / 8 only; at boost level 1 a 5 G-probe partition laid out 1024 x 256 segments of 20 k
+      // records = 5.3 G, the offsets of the last 200 buckets wrapped and those slices came out wrong -- found by the
+      // full-size fixture of config #3 on grouped reads.)
+      auto est_layout = [&](u32 sub) -> u64 {
+        const u64 nst = (m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub);
+        const u64 nk_ = c->n_distinct_k + c->n_distinct_k / 16;
+        const u64 per_keys_ = (nk_ + P3_NWG - 1) / P3_NWG;
+        return (u64)std::min<u64>(nst, P3_NB) * P3_NWG * segcap_for(c, (double)per_keys_ * H / (double)(nst ? nst : 1));
+      };
       auto fits = [&](u32 sub) {
         const u32 sw = sweeps_for(sub);
-        return (sw == 1 || (est && sw <= 64)) && n_pos / sw + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit;
+        return (sw == 1 || (est && sw <= 64)) && n_pos / sw + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit &&
+               (!est || est_layout(sub) < pos_limit);
       };
       u32 sub_log2 = (u32)c->bloom_sub_opt;  // (tests force parts on small vectors)
       while (sub_log2 < 2 && slice_log2 == 20 && sweeps_for(sub_log2) > 1 && fits(sub_log2 + 1)) sub_log2++;
@@ -344,7 +356,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       const u64 ns_total = (m + ((1ull << slice_log2) - 1)) >> slice_log2;
       const u32 sweeps = (u32)((ns_total + P3_NB - 1) / P3_NB);
       const bool sliced = c->bloom_slices_opt && (sweeps == 1 || (est && sweeps <= 64)) &&
-                          n_pos / sweeps + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit;
+                          n_pos / sweeps + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit &&
+                          (!est || est_layout(0) < pos_limit);  // (slice_log2 includes sub_log2 by now)
+      if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] probes: kphase %d, %llu keys, slice_log2 %u sub %u sweeps %u ns_total %llu sliced %d est %d\n", c->kphase, (unsigned long long)c->n_distinct_k, slice_log2, sub_log2, sweeps, (unsigned long long)ns_total, (int)sliced, (int)est);
       if (sliced) {
         const size_t lds_bm = ((size_t)1 << (slice_log2 - sub_log2 - 3)) + 64 + P3_VALID_CAP;
         for (u32 sw = 0; sw < sweeps; sw++) {
@@ -518,6 +532,7 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
       int r2 = do_bloom_t<NW>(c, k, m, H);
       c->kphase = 0;
       c->chunk_acc = false;
+      if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] collected group: %llu keys in, rc %d, %llu distinct\n", (unsigned long long)c->dall_n, r2, (unsigned long long)c->n_distinct_k);
       if (r2) return r2;
       nd += c->n_distinct_k;
       c->dall_n = 0;
@@ -537,6 +552,7 @@ int bloom_chunked(p3_ctx* c, u32 k, u64 m, u32 H) {
       } else if (!rc && !(collecting && c->kcollect_pass)) {
         nd += c->n_distinct_k;
       }
+      if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] chunk %u: collecting %d, rc %d, distinct %llu, list %llu of %llu, kxg %u ksbits %u\n", ci, (int)collecting, rc, (unsigned long long)c->n_distinct_k, (unsigned long long)c->dall_n, (unsigned long long)c->dall_cap, c->kxg, c->ksbits);
       c->kphase = 0;
       c->chunk_acc = false;
       if (rc) return rc;

@@ -39,11 +39,11 @@ for n in sorted(agg):
     if not n.startswith("k_"):
         continue
     a = {c: agg[n][c] / max(1, launches[n][c]) for c in agg[n]}
-    size, lds = wg.get(n, (0, 0))
-    wps = wps_default
-    if size:
-        per_cu = max(1, min(2048 // size, (160 * 1024) // lds if lds else 8, 8))
-        wps = size / 64.0 * per_cu / 4.0
+    # (the CSV's LDS_Block_Size does not include dynamic LDS, so the residency is stated here: the kernels that hold a
+    # 128-150 KB stager or table keep ONE 1024-thread workgroup per CU, everything else fills the CU's 32 wave slots)
+    one_per_cu = ("k_part_scatter_pos", "k_part_countq", "k_part_count", "k_kmer_scatter", "k_kmer_dedup", "k_pos_scatter",
+                  "k_u32_scatter", "k_split", "k_keys_scatter")
+    wps = 4.0 if n in one_per_cu else 8.0
     wc = a.get("SQ_WAVE_CYCLES", 0.0)
     k = {"launches_profiled": launches[n].get("SQ_WAVE_CYCLES", 0), "waves_per_simd": wps,
          "valu_insts": a.get("SQ_INSTS_VALU"), "salu_insts": a.get("SQ_INSTS_SALU"), "lds_insts": a.get("SQ_INSTS_LDS"),

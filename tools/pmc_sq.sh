@@ -11,3 +11,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR S
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/${tag}_$i -o run -- python3 $R/tools/exp_kernels.py 31 quick > $R/gpurun_out/${tag}_$i.log 2>&1 || exit 1
 done
 python3 $R/tools/pmc_agg.py $R/gpurun_out/${tag}_1 $R/gpurun_out/${tag}_2 $R/gpurun_out/${tag}_3 > $R/gpurun_out/${tag}_summary.txt
+python3 $R/tools/pmc_ceilings.py 130000000 4 $R/gpurun_out/${tag}_1 $R/gpurun_out/${tag}_2 $R/gpurun_out/${tag}_3 > $R/gpurun_out/${tag}_ceilings.json
