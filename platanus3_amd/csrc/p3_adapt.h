@@ -9,6 +9,7 @@
 //                         partition would outgrow device memory), then est_ok = false: exact offsets (histogram + scan);
 //                         a further overflow with exact first-level offsets clears chunk_ok (position chunks off: the
 //                         direct kernels take over)
+//   probes overflowed     probe_boost 0 -> 1 -> 2, then est_ok = false (the probe partition keeps a level of its own)
 //   collection overflowed kcollect_ok = false: the chunks' distinct k-mers are probed chunk by chunk
 //   run records failed    one retry at one record per window (sk_boost), then sk_ok = false: per-window kernels
 //   new reads / drop_hints  everything back to the optimistic state (reset)
@@ -17,6 +18,9 @@
 
 struct P3Adapt {
   uint32_t est_boost = 0;    // skew response level of the estimated capacities: 0 / 1 / 2
+  uint32_t probe_boost = 0;  // the same for the probe partition alone: its records are hashes of DISTINCT keys, spread
+                             // evenly whatever the reads look like, so it does not follow est_boost (reads grouped by
+                             // neighbourhood sit at level 1: a workgroup's windows repeat each key ~coverage times)
   bool est_ok = true;        // estimated capacities are in use (until new reads arrive)
   bool chunk_ok = true;      // the position-chunk form is in use for inputs beyond 2^30 positions
   bool kcollect_ok = true;   // the chunks' distinct k-mers are collected and probed once
@@ -28,6 +32,7 @@ struct P3Adapt {
 
   void reset(bool new_reads) {
     est_boost = 0;
+    probe_boost = 0;
     est_ok = chunk_ok = kcollect_ok = sk_ok = true;
     sk_boost = 0;
     hint_valid = false;
@@ -38,6 +43,11 @@ struct P3Adapt {
     fallbacks++;
     if (!est_ok) chunk_ok = false;
     if (est_boost < top && boost_allowed) est_boost++;
+    else est_ok = false;
+  }
+  void probes_overflowed() {
+    fallbacks++;
+    if (probe_boost < 2) probe_boost++;
     else est_ok = false;
   }
   void collection_overflowed() { kcollect_ok = false; }

@@ -72,6 +72,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (!c->spec) {
     HIPCHK(c, zero_bloom());
     HIPCHK(c, hipMemsetAsync(st + 8, 0, 18 * 8, c->stream));  // st[26..] carries the count stage's flags
+    HIPCHK(c, hipMemsetAsync(st + 34, 0, 8, c->stream));      // the probe partition's own overflow flag
   }
   HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
   if (have_s || c->kphase == 2) {
@@ -343,7 +344,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         const u64 nst = (m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub);
         const u64 nk_ = c->n_distinct_k + c->n_distinct_k / 16;
         const u64 per_keys_ = (nk_ + P3_NWG - 1) / P3_NWG;
-        return (u64)std::min<u64>(nst, P3_NB) * P3_NWG * segcap_for(c, (double)per_keys_ * H / (double)(nst ? nst : 1));
+        return (u64)std::min<u64>(nst, P3_NB) * P3_NWG * segcap_at((double)per_keys_ * H / (double)(nst ? nst : 1), c->ad.probe_boost);
       };
       auto fits = [&](u32 sub) {
         const u32 sw = sweeps_for(sub);
@@ -368,14 +369,14 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
             const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
             const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
-            const u32 segcap_p = segcap_for(c, (double)per_keys * H / (double)ns_total);
+            const u32 segcap_p = segcap_at((double)per_keys * H / (double)ns_total, c->ad.probe_boost);
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)
 #define POS_SCATTER(MULTI, M32, SB)                                                                                            \
   LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, MULTI, M32>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,     \
              (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p, (const u64*)(st + 12), (u64)0, \
-             st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 25}), SB, ns)
+             st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), SB, ns)
             const bool m32 = m < (1ull << 32);
             if (sweeps > 1) {
               if (m32) POS_SCATTER(true, true, sbase);
@@ -447,6 +448,11 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   if (c->kphase == 2 && hall[27]) {
     c->ad.collection_overflowed();  // (the per-chunk form still works: no need to give up the estimates altogether)
     return fail(c, P3_ERETRY_INTERNAL, "collected k-mer partition: estimated segment capacity exceeded");
+  }
+  if (hall[34]) {  // the probe partition (hashes of distinct keys) keeps a boost level of its own
+    c->ad.probes_overflowed();
+    return fail(c, P3_ERETRY_INTERNAL, "probe partition: estimated segment capacity exceeded (level now %u%s)", c->ad.probe_boost,
+                c->ad.est_ok ? "" : ", exact next");
   }
   if (hall[25] || hall[26]) {  // an estimated-capacity segment overflowed (skewed keys): repeat with exact offsets
     est_overflowed(c);

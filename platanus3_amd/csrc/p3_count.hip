@@ -56,14 +56,14 @@ bool part_applicable(const p3_ctx* c) { return c->n_words * 32 + 16ull * P3_NWG 
 // hash-spread (low-complexity repeats: one 21-mer with thousands of instances) overflow such a segment; the response
 // is graded (est_overflowed): the stage is repeated with 50 %, then 150 % of the mean on top, and only then with
 // exact offsets (histogram + scan) -- which the position-chunk form of large inputs does not have.
-u32 segcap_for(const p3_ctx* c, double mean) {
+u32 segcap_at(double mean, u32 level) {
   // (the constant slack matters for tiny means only; every 16 records of capacity is 16 records of gap the readers
   // step over, ~2.4 % of a 672-record segment)
   static const double boost[3] = {0.0, 0.5, 1.5};
-  const double v = mean * (1.0 + boost[c->ad.est_boost < 3 ? c->ad.est_boost : 2]) + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) +
-                   (mean >= 256.0 ? 16.0 : 32.0);
+  const double v = mean * (1.0 + boost[level < 3 ? level : 2]) + 6.0 * std::sqrt(mean > 0 ? mean : 0.0) + (mean >= 256.0 ? 16.0 : 32.0);
   return ((u32)v + 15u) & ~15u;
 }
+u32 segcap_for(const p3_ctx* c, double mean) { return segcap_at(mean, c->ad.est_boost); }
 
 // an estimated-capacity segment overflowed: next boost level, or no more estimates for these reads
 void est_overflowed(p3_ctx* c) {

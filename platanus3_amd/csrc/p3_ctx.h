@@ -319,6 +319,7 @@ inline int nw_of(u32 k) { return (2 * k + 63) / 64; }
 int do_count_direct(p3_ctx* c);
 bool part_applicable(const p3_ctx* c);
 u32 segcap_for(const p3_ctx* c, double mean);
+u32 segcap_at(double mean, u32 level);
 void est_overflowed(p3_ctx* c);
 bool est_mode(const p3_ctx* c);
 double active_wgs(u64 n_words);

@@ -20,7 +20,7 @@ from . import capi
 # kernel name -> stage whose ALGORITHMIC bytes it is credited with
 STAGE_OF = {
     "k_pack": "count", "k_endmask": "count", "k_count_direct": "count", "k_count_compact": "count",
-    "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count",
+    "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count", "k_part_countq": "count",
     "k_solid_regions": "count", "k_part_scatter_pos": "count", "k_u32_hist": "count", "k_u32_scatter": "count",
     "k_solid_slices": "count",
     "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_bloom_insert": "bloom",
@@ -349,7 +349,7 @@ class Pipeline:
         own = {
             "k_pack": float(L),
             "k_part_scatter": 8.0 * (L - 20), "k_part_scatter_pos": 8.0 * (L - 20),
-            "k_part_count": 8.0 * (L - 20) + 16.0 * D / R,
+            "k_part_count": 8.0 * (L - 20) + 16.0 * D / R, "k_part_countq": 8.0 * (L - 20) + 16.0 * D / R,
             "k_count_direct": 16.0 * (L - 20) + 16.0 * D / R,
             "k_kmer_scatter": float(L), "k_bloom_direct": float(L) + m / (8.0 * R),
             "k_bloom_slices": m / (8.0 * R), "k_bloom_insert": m / (8.0 * R),

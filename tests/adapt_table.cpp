@@ -1,7 +1,8 @@
 // Table-driven walk of P3Adapt (platanus3_amd/csrc/p3_adapt.h): every row = a sequence of events from the reset state and
 // the state it must end in.  Events: E = estimate overflowed (memory allows level 2), e = the same with level 1 as the
 // top, x = estimate overflowed with boosting switched off (tests), C = collection overflowed, S = run records failed
-// (retry larger), s = run records failed (no retry), H = a pass completed (hints valid), D = drop_hints, N = new reads.
+// (retry larger), s = run records failed (no retry), H = a pass completed (hints valid), D = drop_hints, N = new reads,
+// P = the probe partition overflowed (it keeps a level of its own: probe_boost).
 #include <cstdio>
 #include <cstring>
 
@@ -14,6 +15,7 @@ struct Row {
   unsigned sk_boost;
   bool hint_valid;
   unsigned long long fallbacks;
+  unsigned probe_boost = 0;
 };
 
 static const Row table[] = {
@@ -37,6 +39,10 @@ static const Row table[] = {
     {"EEECsHN", 0,    true,  true,  true,  true,  0,  false, 3},   // new reads: the same
     {"EEEND",   0,    true,  true,  true,  true,  0,  false, 3},
     {"NE",      1,    true,  true,  true,  true,  0,  false, 1},
+    {"P",       0,    true,  true,  true,  true,  0,  false, 1, 1},  // the probes' level moves alone
+    {"EPP",     1,    true,  true,  true,  true,  0,  false, 3, 2},
+    {"PPP",     0,    false, true,  true,  true,  0,  false, 3, 2},  // ... and ends in exact offsets like the others
+    {"PPD",     0,    true,  true,  true,  true,  0,  false, 2, 0},
 };
 
 int main() {
@@ -51,6 +57,7 @@ int main() {
         case 'e': a.estimate_overflowed(1, true); break;
         case 'x': a.estimate_overflowed(2, false); break;
         case 'C': a.collection_overflowed(); break;
+        case 'P': a.probes_overflowed(); break;
         case 'S': a.run_records_failed(true); break;
         case 's': a.run_records_failed(false); break;
         case 'H': a.hint_valid = true; break;
@@ -61,7 +68,7 @@ int main() {
     }
     const bool ok = a.est_boost == r.est_boost && a.est_ok == r.est_ok && a.chunk_ok == r.chunk_ok &&
                     a.kcollect_ok == r.kcollect_ok && a.sk_ok == r.sk_ok && a.sk_boost == r.sk_boost &&
-                    a.hint_valid == r.hint_valid && a.fallbacks == r.fallbacks &&
+                    a.hint_valid == r.hint_valid && a.fallbacks == r.fallbacks && a.probe_boost == r.probe_boost &&
                     a.distinct_cap == (saw_new ? 0ull : 77ull);  // (only new reads forget the output size)
     if (!ok) {
       std::printf("row \"%s\": boost %u est %d chunk %d collect %d sk %d skb %u hint %d fallbacks %llu cap %llu\n", r.events,
