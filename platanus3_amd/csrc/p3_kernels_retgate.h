@@ -520,8 +520,8 @@ static __global__ void __launch_bounds__(P3_NB) k_var_caps(u32* __restrict__ cel
 }
 
 // ---- order-independent digest of the (key, count) table: out[0] += sum, out[1] ^= xor of mix(key ^ count * golden) ----
-// (a verification aid for tables too large to export and sort: 50 M reads give ~1 G entries; the same two words are
-// computed by the oracle's streaming form, oracle/p3_oracle_stream.cpp)
+// (a verification aid for tables too large to export and sort: 50 M reads give ~1 G entries; the test fixtures of the
+// full-size configurations carry the same two words)
 template <typename CNT>
 static __global__ void __launch_bounds__(256) k_table_digest(const u64* __restrict__ keys, const CNT* __restrict__ counts, u64 n,
                                                       u64* __restrict__ out) {
