@@ -80,7 +80,7 @@ __device__ __forceinline__ u32 seg_base(const u32* __restrict__ seg_off, u32 buc
 // segment, segb[b] its base.  Flush: thread t inspects row t, the rows with a full chunk are listed per wave
 // (ballot + mbcnt) and drained 16 at a time by groups of 4 lanes (16 B each) -- nothing is moved inside LDS.
 // Needs blockDim.x == P3_NB.  LDS words: P3_STAGE_WORDS.
-#define P3_STAGE_WORDS (P3_NB * 32 + 3 * P3_NB + P3_NB / 2 + 4)
+#define P3_STAGE_WORDS (P3_NB * 32 + 3 * P3_NB + P3_NB + 4)
 static_assert(P3_PART_THREADS == P3_NB, "stager: one thread per row");
 
 struct StageLds {
@@ -88,7 +88,7 @@ struct StageLds {
   u32* cnt;
   u32* wpos;
   u32* segb;
-  unsigned short* list;
+  u32* list32;
   u32* flag;  // two words: "some lane still holds a refused record", alternating per round
 };
 
@@ -98,8 +98,8 @@ __device__ __forceinline__ StageLds stage_layout(u32* lds) {
   s.cnt = lds + P3_NB * 32;
   s.wpos = s.cnt + P3_NB;
   s.segb = s.wpos + P3_NB;
-  s.list = reinterpret_cast<unsigned short*>(s.segb + P3_NB);
-  s.flag = s.segb + P3_NB + P3_NB / 2;
+  s.list32 = s.segb + P3_NB;
+  s.flag = s.segb + P3_NB + P3_NB;
   return s;
 }
 
@@ -116,14 +116,20 @@ __device__ __forceinline__ bool stage_put(const StageLds& s, u32 b, const REC& r
 template <typename REC>
 __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__ out, bool final_flush, const EstSeg est) {
   constexpr u32 CHUNK = Stg<REC>::CHUNK, CAP = Stg<REC>::CAP;
+  static_assert(CAP <= 64, "list entries carry the row's record count in 7 bits beside the row and the ring parity");
   const u32 t = threadIdx.x;
-  u32 n0 = s.cnt[t] & 0x7fffffffu;
+  const u32 v0 = s.cnt[t];
+  u32 n0 = v0 & 0x7fffffffu;
   n0 = n0 < CAP ? n0 : CAP;
   const bool ready = final_flush ? (n0 != 0) : (n0 >= CHUNK);
   const u64 mask = ballot64(ready);
   const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
-  unsigned short* wl = s.list + (t & ~63u);
-  if (ready) wl[rank] = (unsigned short)t;
+  // a list entry carries what the flushing lanes need to know about the row -- index, ring parity, records -- so that
+  // they do not wait for a second look at the counter before they can ask for the row's data (nobody touches a
+  // counter between the barrier in front of the flush and the flush's own update): two dependent LDS round trips
+  // per step instead of three
+  u32* wl = s.list32 + (t & ~63u);
+  if (ready) wl[rank] = t | ((v0 >> 31) << 10) | (n0 << 11);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -132,14 +138,15 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
   for (u32 i0 = 0; i0 < nready; i0 += 16) {
     const u32 idx = i0 + g;
     if (idx < nready) {
-      const u32 b = wl[idx];
-      const u32 v = s.cnt[b];
-      u32 n = v & 0x7fffffffu;
-      n = n < CAP ? n : CAP;
-      const u32 par = v >> 31;
+      const u32 e = wl[idx];
+      const u32 b = e & 1023u, par = (e >> 10) & 1u, n = e >> 11;
       u32 nch = n / CHUNK;
       if (final_flush && (n % CHUNK)) nch++;
       const u32 wp = s.wpos[b];
+      const u32 sb = s.segb[b];
+      const uint4* row = s.rows + b * 8;
+      const uint4 d0 = row[par * 4 + q];
+      const uint4 d1 = row[(par ^ 1u) * 4 + q];
       const bool fits = !(est.segcap && wp + nch * CHUNK > est.segcap);
       if (!fits) {
         // segment full: the chunk is dropped, results are void and the host re-runs with exact offsets.  The write
@@ -147,10 +154,9 @@ __device__ __forceinline__ void stage_flush(const StageLds& s, REC* __restrict__
         // host has seen the flag (single-synchronisation passes) stays inside the segment
         if (q == 0) *est.ovf = 1;
       } else {
-        uint4* dst = reinterpret_cast<uint4*>(out + (u32)(s.segb[b] + wp));  // (u32 sum: variable mode wraps)
-        const uint4* row = s.rows + b * 8;
-        dst[q] = row[par * 4 + q];
-        if (nch == 2) dst[4 + q] = row[(par ^ 1u) * 4 + q];
+        uint4* dst = reinterpret_cast<uint4*>(out + (u32)(sb + wp));  // (u32 sum: variable mode wraps)
+        dst[q] = d0;
+        if (nch == 2) dst[4 + q] = d1;
       }
       if (!final_flush && q == 0) {
         s.cnt[b] = ((par ^ (nch & 1u)) << 31) | (n - nch * CHUNK);
