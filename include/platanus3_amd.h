@@ -263,6 +263,11 @@ int p3_mr_count_recv_alloc(p3_ctx* ctx, const uint64_t* recv_records, void** d_r
 int p3_mr_initial_sbits(p3_ctx* ctx, uint32_t* sbits);
 int p3_mr_count_owned(p3_ctx* ctx, uint32_t sbits, int* overflowed, uint64_t* max_solid_sb);
 uint32_t p3_rs_log2_for(uint64_t max_solid_sb);
+/* Host arithmetic, no device needed (tests): how the H probes of n_keys distinct keys are laid out for an m-bit vector at
+ * a boost level of the estimated capacities: out = {slice_log2, sub_log2, sweeps, records per (bucket, workgroup)
+ * segment, records the fixed-stride layout of one sweep addresses, 1 if the LDS-slice form is used}.  The layout must stay
+ * below 2^32 (32-bit record offsets) whenever out[5] is 1. */
+int p3_probe_plan(uint64_t n_keys, uint32_t H, uint64_t m_bits, uint32_t boost_level, uint64_t out[6]);
 int p3_mr_solid_build(p3_ctx* ctx, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes,
                       uint64_t* owned_bytes, uint64_t* total_bytes);
 /* Return-path gate (gate_mode 2, the default when the input fits): after p3_mr_count_owned the owner holds,

@@ -41,6 +41,52 @@ int seeds_to_set(p3_ctx* c, u32 k) {
   return P3_OK;
 }
 
+}  // namespace
+
+namespace p3i {
+// How the H probe positions of n_keys distinct keys reach an m-bit vector (pure arithmetic: tests/test_abi.py walks it).
+// Slices of 2^slice_log2 bits (<= 2^20: 128 KiB of LDS), 1024 buckets per sweep of the probe partition; a vector of more
+// than 2^30 bits takes several sweeps over the keys (estimated-capacity form only), each keeping the probes of its
+// slices; beyond 2^30 bits a bucket may span two or four LDS slices (k_bloom_slices reads it once per part: every sweep
+// hashes all keys again, reading 4-byte positions twice or four times costs far less).  What bounds a sweep is the 32-bit
+// record offsets of its fixed-stride layout: buckets x workgroups x the segment capacity AT THE BOOST LEVEL IN USE (round
+// 3: the rule used to be positions per sweep + 1/8 only; at level 1 a 5 G-probe partition laid out 1024 x 256 segments
+// of 20 k records = 5.3 G, the offsets of the last 200 buckets wrapped and those slices came out wrong -- found by the
+// full-size fixture of config #3 on grouped reads).
+ProbePlan probe_plan(u64 n_keys, u32 H, u64 m, bool est, u32 boost, u32 pos_limit_log2_opt, u32 sub_opt, bool slices_on) {
+  ProbePlan pl{};
+  u32 slice_log2 = 10;
+  while (slice_log2 < 20 && ((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
+  const u64 n_pos = n_keys * (u64)H;
+  const u64 pos_limit = 1ull << (pos_limit_log2_opt ? pos_limit_log2_opt : (est ? 32 : 31));
+  auto slices_at = [&](u32 sl) { return (m + ((1ull << sl) - 1)) >> sl; };
+  auto sweeps_at = [&](u32 sl) { return (u32)((slices_at(sl) + P3_NB - 1) / P3_NB); };
+  auto segcap_at_sl = [&](u32 sl) {
+    const u64 nst = slices_at(sl), nk = n_keys + n_keys / 16, per_keys = (nk + P3_NWG - 1) / P3_NWG;
+    return segcap_at((double)per_keys * H / (double)(nst ? nst : 1), boost);
+  };
+  auto layout_at = [&](u32 sl) { return (u64)std::min<u64>(slices_at(sl), P3_NB) * P3_NWG * segcap_at_sl(sl); };
+  auto fits = [&](u32 sl) {
+    const u32 sw = sweeps_at(sl);
+    return (sw == 1 || (est && sw <= 64)) && n_pos / sw + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit &&
+           (!est || layout_at(sl) < pos_limit);
+  };
+  u32 sub_log2 = sub_opt;  // (tests force parts on small vectors)
+  while (sub_log2 < 2 && slice_log2 == 20 && sweeps_at(slice_log2 + sub_log2) > 1 && fits(slice_log2 + sub_log2 + 1)) sub_log2++;
+  slice_log2 += sub_log2;
+  pl.slice_log2 = slice_log2;
+  pl.sub_log2 = sub_log2;
+  pl.ns_total = slices_at(slice_log2);
+  pl.sweeps = sweeps_at(slice_log2);
+  pl.segcap = est ? segcap_at_sl(slice_log2) : 0;
+  pl.layout_records = est ? layout_at(slice_log2) : 0;
+  pl.sliced = slices_on && fits(slice_log2);
+  return pl;
+}
+}  // namespace p3i
+
+namespace {
+
 // Bloom stage.  Gate (S bits) first, then either the direct form (H probes per passing window) or the
 // dedup form (partition passing canonical k-mers, LDS set per sub-bucket, H probes per distinct key).
 template <int NW>
@@ -103,6 +149,15 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     // (kphase 2: the list holds same-bucket runs, one per chunk and dedup cell, and the scatter deals them out in
     // 16-key tiles, so a (bucket, workgroup) segment receives its share give or take a tile per run: extra margin)
     u32 segcap_k = est ? segcap_for(c, mean_k) + (c->kphase == 2 ? c->chunks * 64u : 0u) : 0;
+    // (fixed-stride segments are addressed by 32-bit record offsets: a partition whose layout would not fit them -- a
+    // collected list of billions of keys at a boosted level -- is not laid out at all)
+    if (est && (u64)P3_NB * P3_NWG * segcap_k >= (1ull << 32)) {
+      if (c->kphase == 2) {
+        c->ad.collection_overflowed();
+        return fail(c, P3_ERETRY_INTERNAL, "collected k-mer partition: %u records per segment do not fit 32-bit offsets", segcap_k);
+      }
+      return fail(c, P3_ECAPACITY, "k-mer partition: %u records per segment do not fit 32-bit offsets", segcap_k);
+    }
     // run-length records for the passing k-mers (k <= 32; p3_kernels_sk.h): the count stage used them, so the reads
     // are known to suit them
     const bool sk_k = NW == 1 && est && c->kphase == 0 && c->part_sk && sk_on(c) && c->s_ready;
@@ -323,42 +378,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         c->kxg_all_k = k;
       }
       if (!c->spec) c->n_distinct_k = h[0];
-      // slices of 2^slice_log2 bits (<= 2^20: 128 KiB of LDS), 1024 per sweep; a vector of more than 2^30 bits takes
-      // several sweeps over the distinct keys (estimated-capacity form only), each keeping the probes of its slices
-      u32 slice_log2 = 10;
-      while (slice_log2 < 20 && ((m + ((1ull << slice_log2) - 1)) >> slice_log2) > P3_NB) slice_log2++;
-      // beyond 2^30 bits: buckets of two or four LDS slices (k_bloom_slices reads a bucket once per part) -- every sweep
-      // of the probe partition hashes all keys again, reading 4-byte positions twice or four times costs far less
-      // (as few sweeps as the 2^31 positions of one partition allow: a sweep's positions must fit 32-bit record indices)
+      // how the H probes of the distinct keys reach the vector: slices, sweeps, parts and segment capacity (probe_plan)
+      const ProbePlan plan = probe_plan(c->n_distinct_k, H, m, est, c->ad.probe_boost, (u32)c->pos_limit_log2_opt, (u32)c->bloom_sub_opt,
+                                        c->bloom_slices_opt != 0);
       const u64 n_pos = c->n_distinct_k * (u64)H;  // spec: last pass's count; the scatter checks the real one
-      // records one probe partition may hold: its offsets are unsigned 32-bit (fixed-stride segments: 2^32; the exact
-      // form's scan keeps a bit in hand).  50 M reads on one GPU: two sweeps instead of four, pass 281 -> 266 ms, same vector.
-      const u64 pos_limit = 1ull << (c->pos_limit_log2_opt ? c->pos_limit_log2_opt : (est ? 32 : 31));
-      auto sweeps_for = [&](u32 sub) { return (u32)((((m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub)) + P3_NB - 1) / P3_NB); };
-      // records the fixed-stride layout of ONE sweep addresses (32-bit record offsets): buckets x workgroups x the
-      // segment capacity -- which carries the boost of the current estimate level.  (Round 3: the rule used to be
-      // n_pos / sweeps + n_pos / 8 only; at boost level 1 a 5 G-probe partition laid out 1024 x 256 segments of 20 k
-      // records = 5.3 G, the offsets of the last 200 buckets wrapped and those slices came out wrong -- found by the
-      // full-size fixture of config #3 on grouped reads.)
-      auto est_layout = [&](u32 sub) -> u64 {
-        const u64 nst = (m + ((1ull << (slice_log2 + sub)) - 1)) >> (slice_log2 + sub);
-        const u64 nk_ = c->n_distinct_k + c->n_distinct_k / 16;
-        const u64 per_keys_ = (nk_ + P3_NWG - 1) / P3_NWG;
-        return (u64)std::min<u64>(nst, P3_NB) * P3_NWG * segcap_at((double)per_keys_ * H / (double)(nst ? nst : 1), c->ad.probe_boost);
-      };
-      auto fits = [&](u32 sub) {
-        const u32 sw = sweeps_for(sub);
-        return (sw == 1 || (est && sw <= 64)) && n_pos / sw + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit &&
-               (!est || est_layout(sub) < pos_limit);
-      };
-      u32 sub_log2 = (u32)c->bloom_sub_opt;  // (tests force parts on small vectors)
-      while (sub_log2 < 2 && slice_log2 == 20 && sweeps_for(sub_log2) > 1 && fits(sub_log2 + 1)) sub_log2++;
-      slice_log2 += sub_log2;
-      const u64 ns_total = (m + ((1ull << slice_log2) - 1)) >> slice_log2;
-      const u32 sweeps = (u32)((ns_total + P3_NB - 1) / P3_NB);
-      const bool sliced = c->bloom_slices_opt && (sweeps == 1 || (est && sweeps <= 64)) &&
-                          n_pos / sweeps + n_pos / 8 + 16ull * P3_NWG * P3_NB < pos_limit &&
-                          (!est || est_layout(0) < pos_limit);  // (slice_log2 includes sub_log2 by now)
+      const u32 slice_log2 = plan.slice_log2, sub_log2 = plan.sub_log2, sweeps = plan.sweeps;
+      const u64 ns_total = plan.ns_total;
+      const bool sliced = plan.sliced;
       if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] probes: kphase %d, %llu keys, slice_log2 %u sub %u sweeps %u ns_total %llu sliced %d est %d\n", c->kphase, (unsigned long long)c->n_distinct_k, slice_log2, sub_log2, sweeps, (unsigned long long)ns_total, (int)sliced, (int)est);
       if (sliced) {
         const size_t lds_bm = ((size_t)1 << (slice_log2 - sub_log2 - 3)) + 64 + P3_VALID_CAP;
@@ -369,7 +395,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
             const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
             const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
-            const u32 segcap_p = segcap_at((double)per_keys * H / (double)ns_total, c->ad.probe_boost);
+            const u32 segcap_p = plan.segcap;
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)

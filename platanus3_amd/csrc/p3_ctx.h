@@ -393,6 +393,14 @@ struct ChunkView {
   ~ChunkView() { restore(); }
 };
 
+// ---- p3_bloom.hip --------------------------------------------------------------------------------------------------
+struct ProbePlan {
+  u32 slice_log2, sub_log2, sweeps, segcap;
+  u64 ns_total, layout_records;
+  bool sliced;
+};
+ProbePlan probe_plan(u64 n_keys, u32 H, u64 m, bool est, u32 boost, u32 pos_limit_log2_opt, u32 sub_opt, bool slices_on);
+
 // ---- p3_exchange.hip: the communicator's collectives for the other units ----------------------------------------------
 int xc_a2av(p3_comm* cm, const void* d_send, const u64* soff, const u64* scnt, void* d_recv, const u64* roff, const u64* rcnt,
             u32 elem, hipStream_t st);

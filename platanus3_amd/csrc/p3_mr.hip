@@ -138,6 +138,18 @@ int p3_mr_count_owned(p3_ctx* c, uint32_t sbits, int* overflowed, uint64_t* max_
 
 uint32_t p3_rs_log2_for(uint64_t max_solid_sb) { return rs_log2_for(max_solid_sb); }
 
+int p3_probe_plan(uint64_t n_keys, uint32_t H, uint64_t m_bits, uint32_t boost_level, uint64_t out[6]) {
+  if (!out || !m_bits) return P3_EBADARG;
+  const ProbePlan pl = probe_plan(n_keys, H, m_bits, true, boost_level, 0, 0, true);
+  out[0] = pl.slice_log2;
+  out[1] = pl.sub_log2;
+  out[2] = pl.sweeps;
+  out[3] = pl.segcap;
+  out[4] = pl.layout_records;
+  out[5] = pl.sliced ? 1 : 0;
+  return P3_OK;
+}
+
 int p3_mr_solid_build(p3_ctx* c, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes, uint64_t* owned_bytes,
                       uint64_t* total_bytes) {
   if (!c || !d_solid || !owned_offset_bytes || !owned_bytes || !total_bytes) return P3_EBADARG;

@@ -75,3 +75,31 @@ def test_group_of_ranks_reduces_on_the_host():
     h = C.c_void_p()
     assert L.p3_group_create(C.byref(h), 0, None) != 0
     assert L.p3_group_create(C.byref(h), 65, None) != 0
+
+
+def test_probe_partition_layout_stays_within_its_32_bit_offsets():
+    """p3_probe_plan (host arithmetic of the Bloom stage, no GPU): whenever the LDS-slice form is chosen, the fixed-stride
+    layout of one sweep -- buckets x workgroups x the segment capacity AT THE BOOST LEVEL -- stays below 2^32 records.
+    Round 2's rule looked at the positions per sweep only: config #3 (265 M distinct k-mers, H = 19, m = 3.3 G bits) at
+    boost level 1 laid out 5.3 G records and the last 200 buckets' offsets wrapped (0.03 % of the vector wrong)."""
+    import ctypes as C
+    from platanus3_amd import capi
+    L = capi.load()
+    out = (C.c_uint64 * 6)()
+    seen_multi = False
+    for n_keys in (5_300_000, 88_000_000, 264_787_650, 400_000_000, 1_200_000_000):
+        for m in (66_855_782, 3_342_789_109, 9_057_880_166, 1 << 30, (1 << 32) - 5):
+            for H in (10, 19):
+                for boost in (0, 1, 2):
+                    assert L.p3_probe_plan(n_keys, H, m, boost, out) == 0
+                    slice_log2, sub, sweeps, segcap, layout, sliced = [int(x) for x in out]
+                    if sliced:
+                        assert layout < (1 << 32), (n_keys, m, H, boost, list(out))
+                        assert sweeps * 1024 >= (m + (1 << slice_log2) - 1) >> slice_log2
+                        seen_multi = seen_multi or sweeps > 1
+    assert seen_multi
+    # the case that went wrong: level 0 may use buckets of two slices (2 sweeps), level 1 must not
+    assert L.p3_probe_plan(264_787_650, 19, 3_342_789_109, 0, out) == 0 and int(out[5]) == 1 and int(out[4]) < (1 << 32)
+    lvl0 = (int(out[1]), int(out[2]))
+    assert L.p3_probe_plan(264_787_650, 19, 3_342_789_109, 1, out) == 0 and int(out[4]) < (1 << 32)
+    assert (int(out[1]), int(out[2])) != lvl0 or int(out[5]) == 0
