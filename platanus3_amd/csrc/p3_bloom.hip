@@ -386,6 +386,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       const u64 ns_total = plan.ns_total;
       const bool sliced = plan.sliced;
       if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] probes: kphase %d, %llu keys, slice_log2 %u sub %u sweeps %u ns_total %llu sliced %d est %d\n", c->kphase, (unsigned long long)c->n_distinct_k, slice_log2, sub_log2, sweeps, (unsigned long long)ns_total, (int)sliced, (int)est);
+      bool rec16 = false;
       if (sliced) {
         const size_t lds_bm = ((size_t)1 << (slice_log2 - sub_log2 - 3)) + 64 + P3_VALID_CAP;
         for (u32 sw = 0; sw < sweeps; sw++) {
@@ -395,7 +396,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             // probes are uniform over the vector: every (slice, workgroup) segment gets mean + 6 sigma
             const u64 nk = c->n_distinct_k + c->n_distinct_k / 16;  // spec: last pass's count plus margin
             const u64 per_keys = (nk + P3_NWG - 1) / P3_NWG;
-            const u32 segcap_p = plan.segcap;
+            // 2-byte records where the in-slice offsets fit them (a chunk then holds 32 records: capacities in multiples of 32)
+            rec16 = slice_log2 <= 16 && sub_log2 == 0 && sweeps == 1 && c->probe16_opt != 1;
+            const u32 segcap_p = rec16 ? ((plan.segcap + 31u) & ~31u) : plan.segcap;
+            c->probe_rec_bytes = rec16 ? 2 : 4;
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)
@@ -404,7 +408,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
              (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p, (const u64*)(st + 12), (u64)0, \
              st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), SB, ns)
             const bool m32 = m < (1ull << 32);
-            if (sweeps > 1) {
+            if (rec16) {  // (one sweep, m < 2^26: 2-byte in-slice offsets)
+              LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false, true, unsigned short>), P3_NWG, P3_PART_THREADS, lds_sc,
+                         (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p,
+                         (unsigned short*)c->ppart.p, (const u64*)(st + 12), (u64)0, st + 24,
+                         (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), 0u, ns);
+            } else if (sweeps > 1) {
               if (m32) POS_SCATTER(true, true, sbase);
               else POS_SCATTER(true, false, sbase);
             } else {
@@ -423,9 +432,14 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                        (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
           }
           if (c->n_ranks > 1 || bwords_padded != bwords) HIPCHK(c, zero_bloom());  // (the slices cover words below bwords)
-          LAUNCH_LDS(c, "k_bloom_slices", k_bloom_slices, ns << sub_log2, 1024, lds_bm, (const u32*)c->ppart.p,
-                     (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
-                     (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase, sub_log2);
+          if (rec16)
+            LAUNCH_LDS(c, "k_bloom_slices", (k_bloom_slices<unsigned short>), ns << sub_log2, 1024, lds_bm, (const unsigned short*)c->ppart.p,
+                       (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
+                       (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase, sub_log2);
+          else
+            LAUNCH_LDS(c, "k_bloom_slices", (k_bloom_slices<u32>), ns << sub_log2, 1024, lds_bm, (const u32*)c->ppart.p,
+                       (const u32*)c->seg_off.p, (const u32*)c->ghist.p, slice_log2, bwords * 2, (u32*)c->bloom.p,
+                       (const u64*)(st + 24), (u32)(c->chunk_acc ? 1u : 0u), sbase, sub_log2);
         }
         c->bloom_mode = 3;
       } else {

@@ -103,7 +103,14 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
         const u32 nvalid = nval[u] & 31u;
         tags[u] = nval[u] >> 8;
         const u32 first = ((j0 + u * B) % VPC) * RPV;
-        if constexpr (sizeof(REC) == 4) {
+        if constexpr (sizeof(REC) == 2) {
+          const u32 w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (u32 t = 0; t < 4; t++) {
+            recs[8 * u + 2 * t] = (REC)(w4[t] & 0xffffu);
+            recs[8 * u + 2 * t + 1] = (REC)(w4[t] >> 16);
+          }
+        } else if constexpr (sizeof(REC) == 4) {
           recs[4 * u + 0] = v[u].x;
           recs[4 * u + 1] = v[u].y;
           recs[4 * u + 2] = v[u].z;

@@ -316,6 +316,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
     // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
     forget_learnt(c, false);
+  } else if (n == "probe_records") {
+    if (value < 0 || value > 1) return fail(c, P3_EBADARG, "probe_records must be 0 (2-byte where they fit) or 1 (4-byte only)");
+    c->probe16_opt = (int)value;
   } else if (n == "count_slots") {
     if (value < 0 || value > 1) return fail(c, P3_EBADARG, "count_slots must be 0 (4-byte quotient slots where they apply) or 1 (8-byte slots only)");
     c->countq_opt = (int)value;
@@ -358,6 +361,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "kmer_groups") *value = (int64_t)c->kgroups;
   else if (n == "est_level") *value = c->ad.est_ok ? (int64_t)c->ad.est_boost : 3;  // 0..2 = boost level in use, 3 = exact
   else if (n == "pass_replayed") *value = c->last_pass_replayed ? 1 : 0;
+  else if (n == "probe_record_bytes") *value = (u64)c->probe_rec_bytes;
   else if (n == "quotient_tables") *value = c->q_tables;
   else if (n == "quotient_redone") {  // tables the quotient-slot count left to k_part_count (heavy keys, crowded tables)
     *value = 0;

@@ -733,12 +733,14 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_keys_scatter(const u
   });
 }
 
-template <int NW, bool MULTI, bool M32 = false>  // MULTI: one of several sweeps over a vector of more than 1024 slices; M32: m < 2^32
+// PREC: the record type -- u32, or unsigned short where the in-slice offsets fit 16 bits (slices of <= 2^16 bits: vectors of
+// up to 2^26 bits, BASELINE config #2): half the bytes of the probe partition, half as many chunk flushes
+template <int NW, bool MULTI, bool M32 = false, typename PREC = u32>  // MULTI: one of several sweeps over a vector of more than 1024 slices; M32: m < 2^32
 // totals[1] = padded record total of this partition (k_part_scan_base); if it exceeds `cap` records the kernel
 // raises *cap_flag and writes nothing (the host re-runs with a larger buffer).
 static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u64* __restrict__ keys, const u64* __restrict__ n_ptr,
                                                                  u32 k, ModM mm, u32 H, u32 slice_log2,
-                                                                 const u32* __restrict__ seg_off, u32* __restrict__ out,
+                                                                 const u32* __restrict__ seg_off, PREC* __restrict__ out,
                                                                  const u64* __restrict__ totals, u64 cap,
                                                                  u64* __restrict__ cap_flag, EstSeg est, u32 slice_base,
                                                                  u32 slice_cnt) {
@@ -751,7 +753,7 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
   extern __shared__ __align__(16) u32 lds[];
   const StageLds stg = stage_layout(lds);
   stage_init(stg, seg_off, est);
-  StageCarry<u32> carry;
+  StageCarry<PREC> carry;
   carry.has = false;
   carry.par = 0;
   carry.bkt = 0;
@@ -772,7 +774,8 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
     }
     const u32 m32 = (u32)mm.m, c32 = (u32)mm.c;
     for (u32 done = 0; done < H; done += PR) {
-      u32 rec[PR], bkt[PR];
+      PREC rec[PR];
+      u32 bkt[PR];
       u32 pend = 0;
 #pragma unroll
       for (int t = 0; t < PR; t++) {
@@ -783,7 +786,7 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
           // [slice_base, slice_base + slice_cnt) and merely steps over the other probes
           const u32 sid = (u32)(pr.r >> slice_log2) - (MULTI ? slice_base : 0u);
           if (!MULTI || sid < slice_cnt) {
-            rec[t] = (u32)pr.r & smask;
+            rec[t] = (PREC)((u32)pr.r & smask);
             bkt[t] = sid;
             pend |= 1u << t;
           }
@@ -791,10 +794,10 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
           else probe_step(pr, mm);
         }
       }
-      stage_round<u32, PR>(stg, out, est, rec, bkt, pend, carry);
+      stage_round<PREC, PR>(stg, out, est, rec, bkt, pend, carry);
     }
   }
-  stage_finish<u32>(stg, out, est, carry);
+  stage_finish<PREC>(stg, out, est, carry);
 }
 
 // one workgroup per slice: LDS bitmap, then a coalesced store of the slice (bloom was zeroed; nothing else
@@ -802,7 +805,8 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
 // sub_log2 > 0: a partition bucket spans 2^sub_log2 LDS-sized slices (vectors beyond 2^30 bits: fewer sweeps of the
 // probe partition, each of which hashes every key again); 2^sub_log2 workgroups read the bucket, each keeping the
 // positions of its part (the 4-byte positions are cheap to read twice or four times; the hashes are not cheap to redo).
-static __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restrict__ part, const u32* __restrict__ seg_off,
+template <typename PREC = u32>
+static __global__ void __launch_bounds__(1024) k_bloom_slices(const PREC* __restrict__ part, const u32* __restrict__ seg_off,
                                                        const u32* __restrict__ ghist, u32 slice_log2, u64 n_u32,
                                                        u32* __restrict__ bloom, const u64* __restrict__ cap_flag,
                                                        u32 accumulate, u32 slice_base, u32 sub_log2) {
@@ -817,10 +821,13 @@ static __global__ void __launch_bounds__(1024) k_bloom_slices(const u32* __restr
   __syncthreads();
   const u32 s = blockIdx.x >> sub_log2, mine = blockIdx.x & ((1u << sub_log2) - 1u);
   const u32 pmask = (1u << part_log2) - 1u;
-  bucket_for_each<u32>(part, seg_off, ghist, s, valid, sc + 8, [&](u32 (&r)[16], u32 act) {
+  constexpr int NB_ = 64 / (int)sizeof(PREC);  // records per reader batch
+  bucket_for_each<PREC>(part, seg_off, ghist, s, valid, sc + 8, [&](PREC (&r)[NB_], u32 act) {
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      if ((act & (1u << i)) && (r[i] >> part_log2) == mine) atomicOr(&bm[(r[i] & pmask) >> 5], 1u << (r[i] & 31));
+    for (int i = 0; i < NB_; i++) {
+      const u32 v = (u32)r[i];
+      if ((act & (1u << i)) && (v >> part_log2) == mine) atomicOr(&bm[(v & pmask) >> 5], 1u << (v & 31));
+    }
   });
   __syncthreads();
   const u64 w0 = ((((u64)(slice_base + s)) << sub_log2) | mine) * words;

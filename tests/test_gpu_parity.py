@@ -1130,3 +1130,29 @@ def test_quotient_slot_count_leaves_heavy_keys_to_the_wide_kernel(oracle):
         assert c.get_info("quotient_tables") > 0 and c.get_info("quotient_redone") == 0
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_probe_records_of_two_and_four_bytes_build_the_same_vector(oracle):
+    """Vectors of up to 2^26 bits are built from 2-byte probe records (the in-slice offset of a 2^16-bit slice), larger
+    ones and the option probe_records=1 from 4-byte records: same vector as the oracle either way, and the vector just
+    above the limit takes the 4-byte form by itself."""
+    b, o = synth.reads(seed=31, total_reads=40000, read_len=150)
+    k = 31
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    assert m < (1 << 26)
+    c = capi.Context(0)
+    try:
+        run_and_compare(c, oracle, (b, o), k, m, H)
+        assert c.get_info("probe_record_bytes") == 2
+        w2 = c.export_bloom()
+        c.set_option("probe_records", 1)
+        c.run_pass(k, m, H)
+        assert c.get_info("probe_record_bytes") == 4
+        assert np.array_equal(w2, c.export_bloom())
+        c.set_option("probe_records", 0)
+        m_big = (1 << 26) + 12345  # 1025 slices of 2^16 bits do not fit one sweep: slices of 2^17 bits, 4-byte records
+        run_and_compare(c, oracle, (b, o), k, m_big, H)
+        assert c.get_info("probe_record_bytes") == 4
+    finally:
+        c.close()
