@@ -11,6 +11,7 @@
 //                         direct kernels take over)
 //   probes overflowed     probe_boost 0 -> 1 -> 2, then est_ok = false (the probe partition keeps a level of its own)
 //   collection overflowed kcollect_ok = false: the chunks' distinct k-mers are probed chunk by chunk
+//   quotient tables redone  an eighth or more of a pass's 4-byte-slot tables flagged: q_ok = false (8-byte slots only)
 //   run records failed    one retry at one record per window (sk_boost), then sk_ok = false: per-window kernels
 //   new reads / drop_hints  everything back to the optimistic state (reset)
 #pragma once
@@ -25,6 +26,7 @@ struct P3Adapt {
   bool chunk_ok = true;      // the position-chunk form is in use for inputs beyond 2^30 positions
   bool kcollect_ok = true;   // the chunks' distinct k-mers are collected and probed once
   bool sk_ok = true;         // run-length records may be used (when asked for)
+  bool q_ok = true;          // the count stage tries 4-byte quotient slots first (until an eighth of its tables had to be redone)
   uint32_t sk_boost = 0;     // 0 = expected run density, 1 = one record per window
   bool hint_valid = false;   // the previous pass's sizes may be replayed
   uint64_t distinct_cap = 0; // count-table outputs of the chunked form (0 = start from the default)
@@ -33,7 +35,7 @@ struct P3Adapt {
   void reset(bool new_reads) {
     est_boost = 0;
     probe_boost = 0;
-    est_ok = chunk_ok = kcollect_ok = sk_ok = true;
+    est_ok = chunk_ok = kcollect_ok = sk_ok = q_ok = true;
     sk_boost = 0;
     hint_valid = false;
     if (new_reads) distinct_cap = 0;

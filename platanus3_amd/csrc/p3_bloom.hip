@@ -484,6 +484,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     return fail(c, P3_ERETRY_INTERNAL, "run records do not fit these reads (unknown bases %u, full segment %llu / %llu, table flag %llu)",
                 unk[0], (unsigned long long)hall[26], (unsigned long long)hall[28], (unsigned long long)hall[3]);
   }
+  if (c->counted) quotient_outcome(c, hall[35]);
   if (hall[24]) return fail(c, P3_ERETRY_INTERNAL, "probe partition larger than its buffer");
   if (c->kphase == 2 && hall[27]) {
     c->ad.collection_overflowed();  // (the per-chunk form still works: no need to give up the estimates altogether)

@@ -363,15 +363,7 @@ int p3_get_info(p3_ctx* c, const char* name, int64_t* value) {
   else if (n == "pass_replayed") *value = c->last_pass_replayed ? 1 : 0;
   else if (n == "probe_record_bytes") *value = (u64)c->probe_rec_bytes;
   else if (n == "quotient_tables") *value = c->q_tables;
-  else if (n == "quotient_redone") {  // tables the quotient-slot count left to k_part_count (heavy keys, crowded tables)
-    *value = 0;
-    if (c->q_tables && c->redo.p) {
-      std::vector<u32> h(c->q_tables);
-      if (hipMemcpy(h.data(), c->redo.p, (size_t)c->q_tables * 4, hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(c, P3_EHIP, "reading the redo flags failed");
-      for (u32 v : h) *value += v ? 1 : 0;
-    }
-  }
+  else if (n == "quotient_redone") *value = c->q_redone;  // tables the quotient-slot count left to k_part_count (heavy keys, crowded tables)
   else if (n == "mr_aggregated") *value = c->agg ? 1 : 0;
   else if (n == "mr_distinct_estimate") *value = (int64_t)c->agg_distinct_est;
   else if (n == "mr_send_records") *value = (int64_t)(c->agg ? c->agg_padded : 0);

@@ -290,6 +290,35 @@ int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
   return P3_OK;
 }
 
+// quotient-slot count of nq tables (p3_kernels_countq.h); the k_part_count launch behind it finds the flags through dstats[33]
+static int launch_countq(p3_ctx* c, bool tagged, u32 nq, size_t lds, const void* part, const void* seg, const void* hist, u32 first_pb,
+                         u32 xbits, u32 sbits_q, u32 n_src) {
+  int rc;
+  u64* st = (u64*)c->dstats.p;
+  if ((rc = ensure(c, c->redo, (size_t)nq * 4))) return rc;
+  const bool weighted = (k2_mode(c) & P3_K2_WEIGHTED) != 0;
+#define P3_LAUNCH_Q(TG, WT)                                                                                                    \
+  LAUNCH_LDS(c, "k_part_countq", (k_part_countq<TG, WT>), nq, 1024, lds, (const u64*)part, (const u32*)seg, (const u32*)hist,   \
+             first_pb, xbits, sbits_q, n_src, (u64*)c->ckeys.p, (u32*)c->ccounts.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,   \
+             (u64*)c->sing_cursor.p, (u32*)c->redo.p)
+  if (tagged && weighted) P3_LAUNCH_Q(true, true);
+  else if (tagged) P3_LAUNCH_Q(true, false);
+  else if (weighted) P3_LAUNCH_Q(false, true);
+  else P3_LAUNCH_Q(false, false);
+#undef P3_LAUNCH_Q
+  c->q_tables += nq;
+  return P3_OK;
+}
+
+void quotient_outcome(p3_ctx* c, u64 redone) {
+  c->q_redone = redone;
+  if (c->q_tables && redone * 8 > c->q_tables) c->ad.q_ok = false;
+}
+
+// whether the quotient-slot count may be tried on these reads (it is given up for them once an eighth of its tables had
+// to be redone: crowded tables or heavy keys everywhere)
+static bool countq_on(const p3_ctx* c, u32 ts_log2) { return c->countq_opt != 1 && c->ad.q_ok && ts_log2 == P3_TS_LOG2_MAX; }
+
 // (2) count the owned buckets from the received blobs (c->rx_* describe them; single rank: the local buffers)
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   int rc;
@@ -337,6 +366,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   if (!c->spec) {  // (replay: part_local has just zeroed every statistics word and nothing wrote these since)
     HIPCHK(c, hipMemsetAsync(st, 0, 5 * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(st + 35, 0, 8, c->stream));
   }
   const u32 ts_log2 = c->part_sk ? (u32)c->sk_ts_log2_opt : (u32)c->ts_log2_opt;
   if (c->part_sk) {
@@ -364,14 +394,9 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
       // one reader per bucket on 4-byte quotient slots (p3_kernels_countq.h): tables of twice the keys, so one split
       // bit less; what such a table cannot hold (a key with >= 1024 instances, a crowded table) is flagged and
       // counted by the launch behind it, which returns at once for everything else
-      const bool q = c->countq_opt != 1 && c->n_ranks == 1 && xbits == 0 && sbits >= 1 && !k2_mode(c) && ts_log2 == P3_TS_LOG2_MAX;
+      const bool q = countq_on(c, ts_log2) && c->n_ranks == 1 && xbits == 0 && sbits >= 1 && !(k2_mode(c) & P3_K2_WEIGHTED);
       if (q) {
-        const u32 nq = rows << (sbits - 1);
-        c->q_tables = nq;
-        if ((rc = ensure(c, c->redo, (size_t)nq * 4))) return rc;
-        LAUNCH_LDS(c, "k_part_countq", k_part_countq, nq, 1024, lds, (const u64*)kpart, (const u32*)kseg, (const u32*)khist,
-                   c->rank * rows, 0u, sbits - 1, (u64*)c->ckeys.p, (u32*)c->ccounts.p, st, (u64*)c->tpos.p,
-                   (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32*)c->redo.p);
+        if ((rc = launch_countq(c, false, rows << (sbits - 1), lds, kpart, kseg, khist, c->rank * rows, 0u, sbits - 1, 1u))) return rc;
         c->k2ext_h[1] = (u64)(uintptr_t)c->redo.p;
         HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
       }
@@ -402,6 +427,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   if (c->part_sk) HIPCHK(c, hipMemcpyAsync(unk, c->unk_flag.p, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  quotient_outcome(c, h[35]);
   if (c->part_sk && (unk[0] || h[26] || h[3] == 2)) {
     sk_failed(c, !unk[0] && h[26] && h[3] != 2);
     return fail(c, P3_ERETRY_INTERNAL, "run records do not fit these reads (unknown bases %u, full segment %llu, table flag %llu)",
@@ -437,10 +463,26 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   const u32 n_src = mr ? c->n_ranks : (chunked ? c->chunks : 1u);
   u32 lg = 0;  // split bits that come from the owner's share of the buckets (multi-rank only)
   while (mr && (1u << lg) < n_src) lg++;
-  const u32 rows_total = mr ? P3_NB / n_src : (u32)P3_NB, xbits = lg + xg;
+  const u32 rows_total = mr ? P3_NB / n_src : (u32)P3_NB;
+  const u32 ts_log2 = (u32)c->ts_log2_opt;
+  // 4-byte quotient slots (p3_kernels_countq.h) hold twice the keys of k_part_count's tables: one sub-bucket bit less, or --
+  // without sub-buckets -- cells of twice the size: half the groups, half the k_split launches.  What such a table
+  // cannot hold is flagged and counted by the k_part_count launch behind it at the split the caller asked for.
+  bool q = countq_on(c, ts_log2) && (sbits >= 1 || xg >= 1);
+  const u32 xg_k = xg, sbits_k = q && !sbits ? 1u : sbits;
+  u32 sbits_q = 0;
+  if (q) {
+    if (sbits) sbits_q = sbits - 1;
+    else xg = xg - 1;
+    if (lg + xg == 0 || (n_src > 1 && (1u << (lg + xg)) < n_src) || lg + xg + sbits_q > 16) {  // (nothing to split; sources need their tag bits)
+      q = false;
+      xg = xg_k;
+    }
+  }
+  const u32 xbits = lg + xg;
   const u32 groups = 1u << xg, rows = rows_total >> xg;
   const u32 first_pb = mr ? c->rank * rows_total : 0u;
-  const u32 nsb = P3_NB << sbits;
+  const u32 nsb = P3_NB << (q ? sbits_k : sbits);
   // worst case one entry per record; position chunks (tens of GB of records) size the table from an estimate of the
   // distinct keys instead -- the count kernel refuses to write past it and the stage is then repeated larger
   u64 maxd = c->rx_records + 1;
@@ -456,8 +498,8 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   HIPCHK(c, hipMemsetAsync(st + 32, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 31, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(st + 35, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
-  const u32 ts_log2 = (u32)c->ts_log2_opt;
   if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
   if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
   if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
@@ -481,6 +523,9 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   }
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
+  if (q) {
+    c->k2ext_h[1] = 0;  // (set once the flag buffer exists: after the first quotient launch)
+  }
   for (u32 g = 0; g < groups; g++) {
     if (var) {
       LAUNCH(c, "k_cell_sample", (k_cell_sample<u64, 0>), P3_NWG, P3_PART_THREADS, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
@@ -494,18 +539,29 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
                (u64*)c->lpart.p,
                (EstSeg{var ? P3_VCAP : segcap, (u32*)c->ghist2.p, st + 26, var ? (const u32*)c->caps.p : nullptr}),
                var ? (const u32*)c->seg_off2.p : nullptr);
+    if (q) {
+      if ((rc = launch_countq(c, n_src > 1, (u32)P3_NB << sbits_q, lds, c->lpart.p, c->seg_off2.p, c->ghist2.p, first_pb + g * rows, xbits,
+                              sbits_q, n_src)))
+        return rc;
+      if (!c->k2ext_h[1] || c->k2ext_h[1] != (u64)(uintptr_t)c->redo.p) {
+        c->k2ext_h[1] = (u64)(uintptr_t)c->redo.p;
+        HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
+      }
+    }
+    const u32 sbits_run = q ? sbits_k : sbits;
     if (n_src > 1) {  // (xbits >= log2 n_src by construction)
       LAUNCH_K2(true, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
-                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
+                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits_run, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
                  (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
     } else {
       LAUNCH_K2(false, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
-                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits, ts_log2,
+                 (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits_run, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
                  (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
     }
   }
+  if (q) HIPCHK(c, hipMemsetAsync(st + 33, 0, 8, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -517,6 +573,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   u64 h[P3_NSTAT];
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  quotient_outcome(c, h[35]);
   if (h[26] || h[27]) {
     const bool var_was = var_caps_on(c);
     const u32 level_was = c->ad.est_boost;
@@ -528,7 +585,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   }
   if (h[31]) {  // the estimated table size was too small: twice as much, at most one entry per record
     c->ad.distinct_cap = maxd * 2;
-    return count_split(c, xg, sbits, overflowed, max_solid_sb);
+    return count_split(c, xg_k, sbits, overflowed, max_solid_sb);
   }
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];

@@ -176,6 +176,7 @@ struct p3_ctx {
   std::vector<u64> g_seqoff_host;
   // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
   bool spec = false;
+  u64 q_redone = 0;                 // quotient-slot tables of the last count that k_part_count had to redo (info "quotient_redone")
   int probe_rec_bytes = 0;          // record width of the last probe partition (info "probe_record_bytes": 2 or 4; 0 = none)
   bool last_pass_replayed = false;  // the last p3_run_pass was the single-synchronisation replay (info "pass_replayed")
   u32 hint_sbits = 1, hint_ksbits = 0, hint_k = 0, hint_H = 0;
@@ -341,6 +342,7 @@ float var_seg_scale();
 float var_boost_mul(const p3_ctx* c);
 int var_caps_prepare(p3_ctx* c);
 u32 k2_mode(const p3_ctx* c);
+void quotient_outcome(p3_ctx* c, u64 redone);  // what the pass's statistics say about the quotient-slot tables (dstats[35])
 int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n);
 int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb);
 int solid_build(p3_ctx* c, u32 rs_log2);

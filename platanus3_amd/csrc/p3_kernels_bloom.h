@@ -468,6 +468,7 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<
   }
   if (threadIdx.x < 16) sc[threadIdx.x] = 0;
   __syncthreads();
+  if (dbg & 8u) return;  // (timing experiments: launch + clear only)
   const u32 sb = blockIdx.x;
   const u32 pb = sb >> sbits;
   const u32 subsel = sb & ((1u << sbits) - 1);
@@ -605,13 +606,15 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<
     drain_item(it);
   }
   __syncthreads();
+  if (dbg & 16u) return;  // (timing experiments: no cursor, no emission)
   if (threadIdx.x == 0) {
     if (sc[6]) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
-    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)sc[0]);
+    const u64 base = (dbg & 2u) ? (u64)blockIdx.x * TS : atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)sc[0]);
     sc[2] = (u32)base;
     sc[3] = (u32)(base >> 32);
   }
   __syncthreads();
+  if (dbg & 4u) return;  // (timing experiments: no emission)
   const u64 base = ((u64)sc[3] << 32) | sc[2];
   const u32 lane = threadIdx.x & 63;
   for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
