@@ -206,11 +206,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                  (const u64*)c->rcw.p, (const u32*)c->endm.p, (u32*)c->P.p, (const u32*)c->S.p, c->n_words, k,
                  (const u32*)c->seg_off.p, (REC*)c->kpart.p, (EstSeg{0, nullptr, nullptr}), st + 8);
     }
-    u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? 2 : 0);  // 16 Ki x 8 B or 4 Ki x 20 B slots
+    // 16-byte keys: 16-byte slots for k <= 63 (k_kmer_dedup16: the claim lives in the key's spare bits), else key + state word
+    const bool d16 = NW == 2 && k <= 63 && c->dedup16_opt != 1 && c->tsk_log2_opt >= 2;
+    u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? (d16 ? 1 : 2) : 0);  // 16 Ki x 8 B, 8 Ki x 16 B or 4 Ki x 20 B slots
     if (c->kpart_sk) ts_log2 = (u32)c->sk_ts_log2_opt;
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
-    const size_t lds = (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS +
-                       16 * 192 * sizeof(REC);
+    const size_t lds = d16 ? ((size_t)16 << ts_log2) + 64 + P3_VCAP_POS
+                           : (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS + 16 * 192 * sizeof(REC);
     u32 sbits = 0, kxg = 0, kxg_next = 0;  // (kxg_next: deepening of the split noted for later passes)
     // plain form: one workgroup per sub-bucket, each reading the whole bucket (2^sbits reads of every record);
     // split form (kxg > 0), for large inputs: the k-mer records are partitioned a second time (k_split) into
@@ -229,6 +231,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         return P3_OK;
       }
       if (!xg) {
+        if constexpr (NW == 2) {
+          if (d16) {
+            LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB << sb, 1024, lds, (const Rec16*)c->kpart.p, (const u32*)c->seg_off.p,
+                       (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst);
+            return P3_OK;
+          }
+        }
         LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sb, 1024, lds, (const REC*)c->kpart.p,
                    (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst,
                    (u32)c->dbg_opt);
@@ -264,8 +273,17 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
                    (REC*)c->klpart.p,
                    (EstSeg{var ? P3_VCAP : segcap2, (u32*)c->ghist2.p, st + 25, var ? (const u32*)c->caps.p : nullptr}),
                    var ? (const u32*)c->seg_off2.p : nullptr);
-        LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB, 1024, lds, (const REC*)c->klpart.p,
-                   (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
+        bool done16 = false;
+        if constexpr (NW == 2) {
+          if (d16) {
+            LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB, 1024, lds, (const Rec16*)c->klpart.p, (const u32*)c->seg_off2.p,
+                       (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst);
+            done16 = true;
+          }
+        }
+        if (!done16)
+          LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB, 1024, lds, (const REC*)c->klpart.p,
+                     (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
       }
       return P3_OK;
     };
@@ -509,6 +527,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if (hall[31] || (c->split_xbits && hall[27]))
       return fail(c, P3_ERETRY_INTERNAL, "count stage: outputs or per-cell layout too small under the previous sizes");
     c->cstats.n_distinct = hall[0];
+    c->dist_epoch = c->reads_epoch;
     c->cstats.n_solid = hall[1];
     c->cstats.max_count = hall[32] ? std::max<u64>(hall[2], 1ull << 32) : hall[2];
     c->cstats.n_windows = hall[5];

@@ -316,6 +316,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
     // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
     forget_learnt(c, false);
+  } else if (n == "kmer_slots") {
+    if (value < 0 || value > 1) return fail(c, P3_EBADARG, "kmer_slots must be 0 (16-byte slots for 32 < k <= 63) or 1 (key + state word)");
+    c->dedup16_opt = (int)value;
   } else if (n == "probe_records") {
     if (value < 0 || value > 1) return fail(c, P3_EBADARG, "probe_records must be 0 (2-byte where they fit) or 1 (4-byte only)");
     c->probe16_opt = (int)value;

@@ -38,6 +38,7 @@ int do_count_direct(p3_ctx* c) {
   HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cstats.n_distinct = h[0];
+  c->dist_epoch = c->reads_epoch;
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[2];
   c->cstats.n_windows = h[3];
@@ -444,6 +445,7 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
+  c->dist_epoch = h[3] ? ~0ull : c->reads_epoch;  // (a count that overflowed a table did not see every key)
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[32] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[32]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];  // this rank's windows (local partition)
@@ -468,21 +470,34 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   // 4-byte quotient slots (p3_kernels_countq.h) hold twice the keys of k_part_count's tables: one sub-bucket bit less, or --
   // without sub-buckets -- cells of twice the size: half the groups, half the k_split launches.  What such a table
   // cannot hold is flagged and counted by the k_part_count launch behind it at the split the caller asked for.
-  bool q = countq_on(c, ts_log2) && (sbits >= 1 || xg >= 1);
-  const u32 xg_k = xg, sbits_k = q && !sbits ? 1u : sbits;
-  u32 sbits_q = 0;
+  // The level is chosen from the distinct keys the previous count of these reads found (none yet: k_part_count alone):
+  // one level coarser than the caller's where the tables then stay below ~18 k keys, else the caller's own (emptier
+  // tables, shorter probe chains).  The k_part_count launch behind it works one level finer than the quotient tables,
+  // so that whatever a flagged table held fits its two 16 Ki-slot tables.
+  bool q = countq_on(c, ts_log2) && c->dist_epoch == c->reads_epoch && c->cstats.n_distinct > 0;
+  const u32 xg_k = xg;
+  u32 sbits_q = sbits;
   if (q) {
-    if (sbits) sbits_q = sbits - 1;
-    else xg = xg - 1;
-    if (lg + xg == 0 || (n_src > 1 && (1u << (lg + xg)) < n_src) || lg + xg + sbits_q > 16) {  // (nothing to split; sources need their tag bits)
-      q = false;
-      xg = xg_k;
+    const double per_cell = (double)c->cstats.n_distinct * 1.08 / ((double)P3_NB * (double)(1u << (xg + sbits)));
+    const double room = 0.9 * P3_Q_LIMIT;
+    bool coarser = per_cell * 2 <= room && (sbits >= 1 || xg >= 1);
+    if (!coarser && per_cell > room) q = false;
+    if (q && coarser) {
+      const u32 xg_c = sbits ? xg : xg - 1, sb_c = sbits ? sbits - 1 : 0u;
+      if (lg + xg_c == 0 || (n_src > 1 && (1u << (lg + xg_c)) < n_src)) coarser = false;  // (nothing to split; sources need their tag bits)
+      else {
+        xg = xg_c;
+        sbits_q = sb_c;
+      }
     }
+    if (q && (lg + xg == 0 || (n_src > 1 && (1u << (lg + xg)) < n_src) || lg + xg + sbits_q + 1 > 16)) q = false;
+    if (!q) xg = xg_k;
   }
+  const u32 sbits_k = q ? sbits_q + 1 : sbits;
   const u32 xbits = lg + xg;
   const u32 groups = 1u << xg, rows = rows_total >> xg;
   const u32 first_pb = mr ? c->rank * rows_total : 0u;
-  const u32 nsb = P3_NB << (q ? sbits_k : sbits);
+  const u32 nsb = P3_NB << sbits_k;
   // worst case one entry per record; position chunks (tens of GB of records) size the table from an estimate of the
   // distinct keys instead -- the count kernel refuses to write past it and the stage is then repeated larger
   u64 maxd = c->rx_records + 1;
@@ -500,7 +515,10 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   HIPCHK(c, hipMemsetAsync(st + 27, 0, 8, c->stream));
   HIPCHK(c, hipMemsetAsync(st + 35, 0, 8, c->stream));
   if (mr) HIPCHK(c, hipMemsetAsync(st + 26, 0, 8, c->stream));
-  if ((rc = ensure(c, c->tpos, ((size_t)nsb << ts_log2) * 8))) return rc;
+  // first-instance pairs: one window per table -- 16 Ki entries for k_part_count's, 32 Ki for a quotient table (which may
+  // be as many as k_part_count's when it runs at the caller's level)
+  const size_t tp_entries = std::max((size_t)nsb << ts_log2, q ? ((size_t)P3_NB << sbits_q) * P3_QS : (size_t)0);
+  if ((rc = ensure(c, c->tpos, tp_entries * 8))) return rc;
   if ((rc = ensure(c, c->singles, (c->rx_records + 16) * 4))) return rc;
   if ((rc = ensure(c, c->sing_cursor, 8 * 2 * P3_MAX_RANKS))) return rc;
   HIPCHK(c, hipMemsetAsync(c->sing_cursor.p, 0, 8 * P3_MAX_RANKS, c->stream));
@@ -543,12 +561,13 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
       if ((rc = launch_countq(c, n_src > 1, (u32)P3_NB << sbits_q, lds, c->lpart.p, c->seg_off2.p, c->ghist2.p, first_pb + g * rows, xbits,
                               sbits_q, n_src)))
         return rc;
-      if (!c->k2ext_h[1] || c->k2ext_h[1] != (u64)(uintptr_t)c->redo.p) {
-        c->k2ext_h[1] = (u64)(uintptr_t)c->redo.p;
+      const u64 flags = (u64)(uintptr_t)c->redo.p;
+      if (c->k2ext_h[1] != flags) {
+        c->k2ext_h[1] = flags;
         HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
       }
     }
-    const u32 sbits_run = q ? sbits_k : sbits;
+    const u32 sbits_run = sbits_k;
     if (n_src > 1) {  // (xbits >= log2 n_src by construction)
       LAUNCH_K2(true, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits_run, ts_log2,
@@ -590,6 +609,7 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   *overflowed = h[3] != 0;
   *max_solid_sb = h[4];
   c->cstats.n_distinct = h[0];
+  c->dist_epoch = h[3] ? ~0ull : c->reads_epoch;  // (a count that overflowed a table did not see every key)
   c->cstats.n_solid = h[1];
   c->cstats.max_count = h[32] ? std::max<u64>(h[2], 1ull << 32) : h[2];  // (h[32]: a u32 counter may have wrapped)
   c->cstats.n_windows = h[5];
@@ -931,14 +951,19 @@ int do_count_chunked(p3_ctx* c, u32 C, bool* overflowed) {
   while (xg < 10 && (total >> xg) / P3_NB > 98304) xg++;
   while ((1u << xg) < C) xg++;
   u64 max_solid = 0;
-  for (u32 sbits = 0;; sbits++) {
+  // (the sub-bucket split that held these reads' keys last time is where the next pass starts)
+  for (u32 sbits = c->chunk_sbits_epoch == c->reads_epoch ? c->chunk_sbits : 0u;; sbits++) {
     if (sbits > 5) {
       *overflowed = true;
       return P3_OK;
     }
     bool ovf = false;
     if ((rc = count_split(c, xg, sbits, &ovf, &max_solid))) return rc;
-    if (!ovf) break;
+    if (!ovf) {
+      c->chunk_sbits = sbits;
+      c->chunk_sbits_epoch = c->reads_epoch;
+      break;
+    }
   }
   c->split_xbits = xg;
   c->cstats.n_windows = total;

@@ -176,6 +176,9 @@ struct p3_ctx {
   std::vector<u64> g_seqoff_host;
   // speculative (single-sync) pass: sizes and splits learnt from the previous pass over the same reads
   bool spec = false;
+  u32 chunk_sbits = 0;              // position chunks: the sub-bucket split of the last count that held every table
+  u64 chunk_sbits_epoch = ~0ull;
+  u64 dist_epoch = ~0ull;           // reads_epoch at which cstats.n_distinct was taken (the quotient-slot count sizes its tables from it)
   u64 q_redone = 0;                 // quotient-slot tables of the last count that k_part_count had to redo (info "quotient_redone")
   int probe_rec_bytes = 0;          // record width of the last probe partition (info "probe_record_bytes": 2 or 4; 0 = none)
   bool last_pass_replayed = false;  // the last p3_run_pass was the single-synchronisation replay (info "pass_replayed")
@@ -200,6 +203,7 @@ struct p3_ctx {
   int sk_dbg = 0;            // timing experiments (results are wrong when non-zero)
   int sk_waves_opt = 16;     // waves per workgroup of the run-record consumers (4..16)
   int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
+  int dedup16_opt = 0;       // 1 = 16-byte k-mers always on the 20-byte-slot sets (tests)
   int probe16_opt = 0;       // 1 = never use 2-byte probe records (tests)
   int countq_opt = 0;        // 0 = count stage on 4-byte quotient slots where they apply (p3_kernels_countq.h), 1 = never
   DevBuf unk_flag;           // set by k_pack when a base is not A/C/G/T

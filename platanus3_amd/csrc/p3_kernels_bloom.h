@@ -632,6 +632,127 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<
   }
 }
 
+// ---- k_kmer_dedup16: the NW == 2 set on 16-byte slots, k <= 63 ------------------------------------------------------
+// k_kmer_dedup<2> spends 20 bytes of LDS per slot (key + a state word for its claim protocol) and 49 KiB on per-wave
+// miss queues: 4 Ki slots per workgroup, so the 10 G windows of BASELINE config #4 take 2,800 launches of 1,024
+// workgroups a pass, each workgroup alive for ~20 us to look at 3 k records.  For k <= 63 the high key word has two
+// spare bits, which is all a claim protocol needs:
+//
+//   thi[slot] = ~0                    empty
+//             = hi                    claimed (64-bit compare-and-swap from ~0); the owner then writes tlo[slot] = lo
+//             = hi | bit 63           ... and publishes; only now may a reader compare lo
+//
+// A reader that finds its own hi unpublished looks again on its next loop iteration (the owner -- possibly a lane of
+// the same wave, in the other branch of the same iteration -- never waits on anybody).  No state word, no queue (long-read
+// k-mers are mostly first instances: the queue's fast path rarely hit): 16 bytes per slot, 8 Ki slots in 128 KiB --
+// twice the keys per workgroup, half the groups, half the k_split launches.  The first probe of all four records of a
+// reader batch is issued before any is resolved.  gstats as k_kmer_dedup.
+#define P3_D16_READY (1ULL << 63)
+static __global__ void __launch_bounds__(1024) k_kmer_dedup16(const Rec16* __restrict__ part, const u32* __restrict__ seg_off,
+                                                        const u32* __restrict__ ghist, u32 sbits, u32 ts_log2,
+                                                        u64* __restrict__ out_keys, u64* __restrict__ gstats) {
+  extern __shared__ __align__(16) u32 lds[];
+  const u32 TS = 1u << ts_log2;
+  u64* thi = reinterpret_cast<u64*>(lds);
+  u64* tlo = thi + TS;
+  u32* sc = reinterpret_cast<u32*>(tlo + TS);
+  for (u32 i = threadIdx.x; i < TS; i += blockDim.x) thi[i] = ~0ULL;
+  if (threadIdx.x < 16) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 sb = blockIdx.x;
+  const u32 pb = sb >> sbits;
+  const u32 subsel = sb & ((1u << sbits) - 1);
+  const u32 limit = TS - (TS >> 3);
+  uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
+  u32 nclaim = 0;
+  bool ovf = false;
+  // (Measured: letting the four records of a batch advance together -- every step issuing its LDS operation for each
+  // of them before any result is used -- was SLOWER, 16.2 against 13.8 ms per pass on 200 k x 10 kbp: the kernel is bound
+  // by the instructions of its divergent loop, ~500 a row of 64 records, not by the round trips; the extra masks cost
+  // more than the overlap saved.)
+  bucket_for_each<Rec16, P3_VCAP_POS>(part, seg_off, ghist, pb, valid, sc + 8, [&](Rec16 (&r)[4], u32 act) {
+    u32 f[4], slot[4];
+    u64 cur[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // the first look of all four records is in flight before any is resolved
+      f[t] = kfold<2>(r[t].lo, r[t].hi);
+      slot[t] = (f[t] * 0x2C1B3C6Du) >> (32 - ts_log2);
+      cur[t] = __hip_atomic_load(&thi[slot[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      bool pending = (act >> t) & 1u;
+      if (sbits) pending = pending && (((f[t] * 0x9E3779B1u) >> (32 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
+      const u64 lo = r[t].lo, hi = r[t].hi;
+      const u32 step = ((f[t] * 0xC2B2AE35u) >> 15) | 1u;
+      u32 s = slot[t], probes = 0;
+      u64 c = cur[t];
+      while (pending) {
+        bool advance = false;
+        if (c == ~0ULL) {
+          const u64 old = atomicCAS((unsigned long long*)&thi[s], ~0ULL, (unsigned long long)hi);
+          if (old == ~0ULL) {  // ours: the low word, then the published high word
+            __hip_atomic_store(&tlo[s], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&thi[s], hi | P3_D16_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nclaim++;
+            pending = false;
+          } else {
+            c = old;  // somebody else's claim: examined on the next iteration
+          }
+        } else if ((c & ~P3_D16_READY) == hi) {
+          if (c & P3_D16_READY) {
+            if (__hip_atomic_load(&tlo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) pending = false;
+            else advance = true;
+          } else {
+            c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // owner between its two stores: look again
+          }
+        } else {
+          advance = true;
+        }
+        if (advance) {
+          // (0.875^128 = 4e-8 at the fullest load the host accepts: a set beyond it; once one lane has seen that, the
+          // others stop walking the full table as well -- the host repeats the stage with a finer split anyway)
+          if (++probes > 128u || ((probes & 7u) == 0 && __hip_atomic_load(&sc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+            if (probes > 128u) __hip_atomic_store(&sc[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ovf = true;
+            pending = false;
+          } else {
+            s = (s + step) & (TS - 1);
+            c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+  });
+  const u32 lane = threadIdx.x & 63;
+  for (int off = 32; off > 0; off >>= 1) nclaim += __shfl_down(nclaim, off, 64);
+  if (lane == 0 && nclaim) atomicAdd(&sc[0], nclaim);
+  if (ovf) sc[6] = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (sc[6] || sc[0] > limit) atomicAdd((unsigned long long*)&gstats[3], 1ULL);
+    const u64 base = atomicAdd((unsigned long long*)&gstats[0], (unsigned long long)sc[0]);
+    sc[2] = (u32)base;
+    sc[3] = (u32)(base >> 32);
+  }
+  __syncthreads();
+  const u64 base = ((u64)sc[3] << 32) | sc[2];
+  for (u32 i0 = 0; i0 < TS; i0 += blockDim.x) {
+    const u32 i = i0 + threadIdx.x;
+    const u64 h = i < TS ? thi[i] : ~0ULL;  // (sets smaller than the workgroup: tests)
+    const bool full = h != ~0ULL;
+    const unsigned long long bal = ballot64(full);
+    u32 wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&sc[1], (u32)__popcll(bal));
+    wbase = __shfl(wbase, 0, 64);
+    if (full) {
+      const u32 idx = wbase + (u32)__popcll(bal & ((1ULL << lane) - 1));
+      out_keys[(base + idx) * 2] = tlo[i];
+      out_keys[(base + idx) * 2 + 1] = h & ~P3_D16_READY;
+    }
+  }
+}
+
 // ---- k_bloom_insert: H probes per distinct key, global atomicOr -------------------------------------------------
 template <int NW>
 static __global__ void __launch_bounds__(256) k_bloom_insert(const u64* __restrict__ keys, const u64* __restrict__ n_ptr, u32 k,

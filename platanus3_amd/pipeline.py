@@ -23,7 +23,7 @@ STAGE_OF = {
     "k_part_hist": "count", "k_part_scan": "count", "k_part_scatter": "count", "k_part_count": "count", "k_part_countq": "count",
     "k_solid_regions": "count", "k_part_scatter_pos": "count", "k_u32_hist": "count", "k_u32_scatter": "count",
     "k_solid_slices": "count",
-    "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_bloom_insert": "bloom",
+    "k_kmer_hist": "bloom", "k_kmer_scatter": "bloom", "k_kmer_dedup": "bloom", "k_kmer_dedup16": "bloom", "k_bloom_insert": "bloom",
     "k_pos_hist": "bloom", "k_pos_scatter": "bloom", "k_bloom_slices": "bloom",
     "k_gate_direct": "bloom", "k_gate_regions": "bloom", "k_bloom_direct": "bloom", "k_seeds": "bloom",
     "k_or_reduce": "bloom",

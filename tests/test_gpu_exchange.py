@@ -172,7 +172,8 @@ def test_run_pass_in_groups(oracle, procs, v, k, gate):
             assert comm.all_reduce([r, 1], "sum") == [V * (V - 1) // 2, V]
             assert comm.all_reduce([r], "max") == [V - 1]
             keys, counts = ctx.export_counts()
-            results[r] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()])
+            results[r] = (keys.copy(), counts.copy(), ctx.export_bloom(), [capi.decode_key(x, k) for x in ctx.export_seeds()],
+                          ctx.get_info("quotient_tables"))
             ctx.close()
             comm.close()
         except Exception as e:  # noqa: BLE001
@@ -191,6 +192,8 @@ def test_run_pass_in_groups(oracle, procs, v, k, gate):
             c.close()
     assert not errors, errors
     _check_union(oracle, b, o, k, m, H, results)
+    if gate == 2:  # (second pass of a rank: its owned cells counted on quotient slots, the sending ranks as source tags)
+        assert all(r[4] > 0 for r in results), [r[4] for r in results]
 
 
 @pytest.mark.parametrize("case_name,procs,v", [("synth2000_k31", 1, 4), ("synth3000_k51", 2, 2), ("long40_k63", 1, 2),

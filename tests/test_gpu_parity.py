@@ -766,6 +766,9 @@ def test_position_chunks_small(oracle, chunks, k):
     c.run_pass(k, m, H)
     c.run_pass(k, m, H)
     assert c.get_info("chunks") == chunks and c.get_info("est_fallbacks") == 0
+    # once a count of these reads has told how many distinct keys there are, the chunks' cells are counted on 4-byte
+    # quotient slots with the chunk of every record as its source tag (p3_kernels_countq.h)
+    assert c.get_info("quotient_tables") > 0 and c.get_info("quotient_redone") == 0
     keys, counts = c.export_counts()
     ekeys, ecounts = oracle.count_short((b, o), min_len=k)
     ebloom, eseeds, _, _ = oracle.make_bf((b, o), ekeys, ecounts, k, m, H)
@@ -1156,3 +1159,31 @@ def test_probe_records_of_two_and_four_bytes_build_the_same_vector(oracle):
         assert c.get_info("probe_record_bytes") == 4
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [33, 47, 63, 64])
+def test_sixteen_byte_kmer_sets_on_both_slot_layouts(oracle, k):
+    """k-mers of 33...63 bases are deduplicated on 16-byte slots whose claim protocol lives in the two spare bits of the
+    high key word (k_kmer_dedup16); k = 64 has no spare bits and stays on key + state word (k_kmer_dedup<2>), which the
+    option kmer_slots=1 selects for the others too: same vector and seeds as the oracle from both, plain form and
+    second-level partition."""
+    b, o = synth.reads(seed=80 + k, total_reads=600, read_len=4000, sub_rate_ppm=10000)
+    m, H = oracle.estimate_bloom(int(b.size), k)
+    for split in (0, 3):
+        for slots in (0, 1):
+            c = capi.Context(0)
+            try:
+                c.set_option("kmer_slots", slots)
+                if split:
+                    c.set_option("kmer_split", split)
+                c.set_profiling(True)
+                words, _ = run_and_compare(c, oracle, (b, o), k, m, H)
+                c.run_pass(k, m, H)
+                assert np.array_equal(words, c.export_bloom())
+                st = c.kernel_stats()
+                used16 = st.get("k_kmer_dedup16", {}).get("launches", 0) > 0
+                used20 = st.get("k_kmer_dedup", {}).get("launches", 0) > 0
+                assert used16 == (slots == 0 and k <= 63) and used20 == (not used16)
+            finally:
+                c.close()
