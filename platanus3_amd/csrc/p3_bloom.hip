@@ -211,7 +211,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     u32 ts_log2 = (u32)c->tsk_log2_opt - (NW == 2 ? (d16 ? 1 : 2) : 0);  // 16 Ki x 8 B, 8 Ki x 16 B or 4 Ki x 20 B slots
     if (c->kpart_sk) ts_log2 = (u32)c->sk_ts_log2_opt;
     u64* dst = st + 16;  // dedup stats block: [0] distinct, [3] overflow; st[24] = probe-partition capacity flag
-    const size_t lds = d16 ? ((size_t)16 << ts_log2) + 64 + P3_VCAP_POS
+    const size_t lds = d16 ? ((size_t)16 << ts_log2) + 64 + P3_VCAP_POS + 16 * (64 + 4 * 64) * 4
                            : (NW == 1 ? ((size_t)8 << ts_log2) : ((size_t)20 << ts_log2)) + 64 + P3_VCAP_POS + 16 * 192 * sizeof(REC);
     u32 sbits = 0, kxg = 0, kxg_next = 0;  // (kxg_next: deepening of the split noted for later passes)
     // plain form: one workgroup per sub-bucket, each reading the whole bucket (2^sbits reads of every record);
@@ -234,7 +234,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if constexpr (NW == 2) {
           if (d16) {
             LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB << sb, 1024, lds, (const Rec16*)c->kpart.p, (const u32*)c->seg_off.p,
-                       (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst);
+                       (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
             return P3_OK;
           }
         }
@@ -277,7 +277,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if constexpr (NW == 2) {
           if (d16) {
             LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB, 1024, lds, (const Rec16*)c->klpart.p, (const u32*)c->seg_off2.p,
-                       (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst);
+                       (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
             done16 = true;
           }
         }

@@ -17,7 +17,9 @@
 // TAGGED: the table entries are 16 bits wide (so the window is VCAP / 2 chunks): the high byte carries
 // (segment index / tag_div) and f gets the tag of each of the four vectors as a third argument (k_part_count: the
 // source -- rank or position chunk -- of a re-partitioned cell's segment group).
-template <typename REC, u32 VCAP = P3_VALID_CAP, bool TAGGED = false, typename F>
+// INDEXED: f gets, as its last argument, the index in `part` of the record recs[0] came from -- recs[i] came from
+// part[that + (i / RPV) * blockDim.x * RPV + i % RPV] (k_kmer_dedup16 queues a record it cannot place at once by index).
+template <typename REC, u32 VCAP = P3_VALID_CAP, bool TAGGED = false, bool INDEXED = false, typename F>
 __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, const u32* __restrict__ seg_off,
                                                 const u32* __restrict__ ghist, u32 pb, uint8_t* valid, u32* sc2,
                                                 F f, u32 seg_begin = 0, u32 seg_count = P3_NWG, u32 tag_div = P3_NWG) {
@@ -127,6 +129,7 @@ __device__ __forceinline__ void bucket_for_each(const REC* __restrict__ part, co
           if (first + t < nvalid) act |= 1u << (u * RPV + t);
       }
       if constexpr (TAGGED) f(recs, act, tags);
+      else if constexpr (INDEXED) f(recs, act, (u32)(start + ((u64)wb * VPC + j0) * RPV));
       else f(recs, act);
     }
     __syncthreads();

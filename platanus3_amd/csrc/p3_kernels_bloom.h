@@ -650,7 +650,7 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup(const typename KRec<
 #define P3_D16_READY (1ULL << 63)
 static __global__ void __launch_bounds__(1024) k_kmer_dedup16(const Rec16* __restrict__ part, const u32* __restrict__ seg_off,
                                                         const u32* __restrict__ ghist, u32 sbits, u32 ts_log2,
-                                                        u64* __restrict__ out_keys, u64* __restrict__ gstats) {
+                                                        u64* __restrict__ out_keys, u64* __restrict__ gstats, u32 dbg) {
   extern __shared__ __align__(16) u32 lds[];
   const u32 TS = 1u << ts_log2;
   u64* thi = reinterpret_cast<u64*>(lds);
@@ -666,11 +666,67 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup16(const Rec16* __res
   uint8_t* valid = reinterpret_cast<uint8_t*>(sc + 16);
   u32 nclaim = 0;
   bool ovf = false;
-  // (Measured: letting the four records of a batch advance together -- every step issuing its LDS operation for each
-  // of them before any result is used -- was SLOWER, 16.2 against 13.8 ms per pass on 200 k x 10 kbp: the kernel is bound
-  // by the instructions of its divergent loop, ~500 a row of 64 records, not by the round trips; the extra masks cost
-  // more than the overlap saved.)
-  bucket_for_each<Rec16, P3_VCAP_POS>(part, seg_off, ghist, pb, valid, sc + 8, [&](Rec16 (&r)[4], u32 act) {
+  // A record that cannot be placed at once -- its home slot holds another key, or it lost the race for it -- is queued
+  // BY INDEX (4 bytes; the 16-byte record is read again, from L2, when its turn comes) in a per-wave LDS queue that is
+  // worked off 64 at a time, one record per lane: the data-dependent probe loop always runs with full lanes.  Measured on
+  // 200 k x 10 kbp, per launch of 1,024 sets: reader alone 84 us, + first attempt 112 us; the leftovers cost another
+  // 116 us when every lane looped over its own (a loop runs as long as its busiest lane), and letting the four records
+  // of a batch advance together inside one loop was slower still (the masks cost more than the overlap saved).
+  constexpr u32 QCAP = 64 + 4 * 64;
+  u32* wq = reinterpret_cast<u32*>(valid + P3_VCAP_POS) + (threadIdx.x >> 6) * QCAP;
+  u32 qn = 0;  // wave-uniform
+  const u32 lane = threadIdx.x & 63;
+  const unsigned long long lt_mask = (1ULL << lane) - 1;
+  auto place = [&](u32 idx) {  // one queued record per lane
+    const uint4 v = reinterpret_cast<const uint4*>(part)[idx];
+    const u64 lo = ((u64)v.y << 32) | v.x, hi = ((u64)v.w << 32) | v.z;
+    const u32 f = kfold<2>(lo, hi);
+    const u32 step = ((f * 0xC2B2AE35u) >> 15) | 1u;
+    u32 s = (f * 0x2C1B3C6Du) >> (32 - ts_log2), probes = 0;
+    u64 c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bool pending = true;
+    while (pending) {
+      bool advance = false;
+      if (c == ~0ULL) {
+        const u64 old = atomicCAS((unsigned long long*)&thi[s], ~0ULL, (unsigned long long)hi);
+        if (old == ~0ULL) {  // ours: the low word, then the published high word
+          __hip_atomic_store(&tlo[s], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&thi[s], hi | P3_D16_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          nclaim++;
+          pending = false;
+        } else {
+          c = old;  // somebody else's claim: examined on the next iteration
+        }
+      } else if ((c & ~P3_D16_READY) == hi) {
+        if (c & P3_D16_READY) {
+          if (__hip_atomic_load(&tlo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) pending = false;
+          else advance = true;
+        } else {
+          c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // owner between its two stores: look again
+        }
+      } else {
+        advance = true;
+      }
+      if (advance) {
+        // (0.875^128 = 4e-8 at the fullest load the host accepts: a set beyond it; once one lane has seen that, the
+        // others stop walking the full table as well -- the host repeats the stage with a finer split anyway)
+        if (++probes > 128u || ((probes & 7u) == 0 && __hip_atomic_load(&sc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+          if (probes > 128u) __hip_atomic_store(&sc[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ovf = true;
+          pending = false;
+        } else {
+          s = (s + step) & (TS - 1);
+          c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  };
+  u64 dsum = 0;
+  bucket_for_each<Rec16, P3_VCAP_POS, false, true>(part, seg_off, ghist, pb, valid, sc + 8, [&](Rec16 (&r)[4], u32 act, u32 rec0) {
+    if (dbg & 32u) {  // (timing experiments: the reader alone)
+      for (int t = 0; t < 4; t++) dsum += ((act >> t) & 1u) ? r[t].lo ^ r[t].hi : 0;
+      return;
+    }
     u32 f[4], slot[4];
     u64 cur[4];
 #pragma unroll
@@ -679,52 +735,51 @@ static __global__ void __launch_bounds__(1024) k_kmer_dedup16(const Rec16* __res
       slot[t] = (f[t] * 0x2C1B3C6Du) >> (32 - ts_log2);
       cur[t] = __hip_atomic_load(&thi[slot[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    // Straight-line first attempt for all four records -- their LDS operations are in flight together: a repeat of a key
+    // that sits in its home slot compares the low word (most records at short-read coverage), an empty home slot is
+    // claimed at once (most records of long reads).
+    u32 todo = 0, claim = 0;
+    u64 l[4], x[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-      bool pending = (act >> t) & 1u;
-      if (sbits) pending = pending && (((f[t] * 0x9E3779B1u) >> (32 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
-      const u64 lo = r[t].lo, hi = r[t].hi;
-      const u32 step = ((f[t] * 0xC2B2AE35u) >> 15) | 1u;
-      u32 s = slot[t], probes = 0;
-      u64 c = cur[t];
-      while (pending) {
-        bool advance = false;
-        if (c == ~0ULL) {
-          const u64 old = atomicCAS((unsigned long long*)&thi[s], ~0ULL, (unsigned long long)hi);
-          if (old == ~0ULL) {  // ours: the low word, then the published high word
-            __hip_atomic_store(&tlo[s], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&thi[s], hi | P3_D16_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            nclaim++;
-            pending = false;
-          } else {
-            c = old;  // somebody else's claim: examined on the next iteration
-          }
-        } else if ((c & ~P3_D16_READY) == hi) {
-          if (c & P3_D16_READY) {
-            if (__hip_atomic_load(&tlo[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) pending = false;
-            else advance = true;
-          } else {
-            c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);  // owner between its two stores: look again
-          }
-        } else {
-          advance = true;
-        }
-        if (advance) {
-          // (0.875^128 = 4e-8 at the fullest load the host accepts: a set beyond it; once one lane has seen that, the
-          // others stop walking the full table as well -- the host repeats the stage with a finer split anyway)
-          if (++probes > 128u || ((probes & 7u) == 0 && __hip_atomic_load(&sc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
-            if (probes > 128u) __hip_atomic_store(&sc[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            ovf = true;
-            pending = false;
-          } else {
-            s = (s + step) & (TS - 1);
-            c = __hip_atomic_load(&thi[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-        }
+      bool mine = (act >> t) & 1u;
+      if (sbits) mine = mine && (((f[t] * 0x9E3779B1u) >> (32 - P3_PBITS - sbits)) & ((1u << sbits) - 1)) == subsel;
+      todo |= mine ? (1u << t) : 0u;
+      l[t] = ~r[t].lo;
+      if (mine && cur[t] == (r[t].hi | P3_D16_READY)) l[t] = __hip_atomic_load(&tlo[slot[t]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (mine && cur[t] == ~0ULL) {
+        claim |= 1u << t;
+        x[t] = atomicCAS((unsigned long long*)&thi[slot[t]], ~0ULL, (unsigned long long)r[t].hi);
       }
     }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if (l[t] == r[t].lo) todo &= ~(1u << t);
+      if (((claim >> t) & 1u) && x[t] == ~0ULL) {  // ours: the low word, then the published high word (the LDS takes a wave's operations in order)
+        __hip_atomic_store(&tlo[slot[t]], r[t].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(&thi[slot[t]], r[t].hi | P3_D16_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nclaim++;
+        todo &= ~(1u << t);
+      }
+    }
+    if (dbg & 64u) todo = 0;  // (timing experiments: reader + first attempt only)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const bool q = (todo >> t) & 1u;
+      const unsigned long long bal = ballot64(q);
+      if (q) wq[qn + (u32)__popcll(bal & lt_mask)] = rec0 + (u32)t * blockDim.x;
+      qn += (u32)__popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    while (qn >= 64) {
+      qn -= 64;
+      place(wq[qn + lane]);
+    }
   });
-  const u32 lane = threadIdx.x & 63;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (lane < qn) place(wq[lane]);
+  if ((dbg & 32u) && dsum == 0x1234567ULL) sc[7] = 1;
   for (int off = 32; off > 0; off >>= 1) nclaim += __shfl_down(nclaim, off, 64);
   if (lane == 0 && nclaim) atomicAdd(&sc[0], nclaim);
   if (ovf) sc[6] = 1;

@@ -16,7 +16,7 @@ for kv in os.environ.get("P3_OPTS", "").split(","):
 c.load_reads(b, o, k)
 for _ in range(3):
     c.run_pass(k, m, H)
-for dbg in (0, 8, 16, 4, 2, 0):
+for dbg in [int(x) for x in os.environ.get('GATES', '0,32,64,0').split(',')]:
     c.set_option("dbg", dbg)
     c.reset_kernel_stats(); c.set_profiling(True)
     try:
@@ -26,7 +26,7 @@ for dbg in (0, 8, 16, 4, 2, 0):
     c.set_profiling(False)
     st = c.kernel_stats()
     print("dbg=%2d  " % dbg + "  ".join("%s=%.2f ms/%d = %.1f us" % (n, v["total_ms"], v["launches"], 1e3 * v["total_ms"] / max(1, v["launches"]))
-                                       for n, v in st.items() if n in ("k_kmer_dedup", "k_split", "k_part_count", "k_part_countq")), flush=True)
+                                       for n, v in st.items() if n in ("k_kmer_dedup", "k_kmer_dedup16", "k_split")), flush=True)
     c.set_option("dbg", 0)
     c.drop_hints() if hasattr(c, "drop_hints") else None
     c.run_pass(k, m, H)
