@@ -178,7 +178,12 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
     if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
     if ((rc = ensure(c, c->kpart, (est ? (u64)P3_NB * P3_NWG * segcap_k : max_records) * sizeof(REC)))) return rc;
-    if ((rc = ensure(c, c->dkeys, ((c->kphase == 2 ? c->dall_n : c->n_words * 32) + 1) * 8 * NW))) return rc;
+    // the distinct keys go to dkeys -- except those of a collected list (kphase 2), which go back into the list's own buffer:
+    // k_keys_scatter has turned the list into its partition by the time the first set is emitted, and at 16 bytes a key
+    // the output of a few billion keys is what decided how many chunks one collection could hold
+    const bool out_in_list = c->kphase == 2 && c->dall_n + 1 <= c->dall_cap;
+    if (!out_in_list && (rc = ensure(c, c->dkeys, ((c->kphase == 2 ? c->dall_n : c->n_words * 32) + 1) * 8 * NW))) return rc;
+    u64* const keys_out = (u64*)(out_in_list ? c->dall.p : c->dkeys.p);
     const size_t lds_sc = (size_t)P3_STAGE_WORDS * 4;
     if (c->kphase == 2) {
       if (!est) return fail(c, P3_ERETRY_INTERNAL, "global k-mer dedup needs the estimated-capacity partition");
@@ -227,19 +232,19 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if (lds_sk > 160u * 1024u) return fail(c, P3_EBADARG, "run-record dedup: %zu bytes of LDS (sk_ts_log2 / sk_waves)", lds_sk);
         if (sb < c->sk_kfbits) return fail(c, P3_EHIP, "run records: k-mer split %u below the scattered fine buckets %u", sb, c->sk_kfbits);
         LAUNCH_LDS(c, "k_sk_dedup", k_sk_dedup, P3_NB << sb, nwaves * 64, lds_sk, (const uint4*)c->kpart.p,
-                   (const u32*)c->ghist.p, c->sk_ksegcap, c->sk_kfbits, sb - c->sk_kfbits, ts_log2, k, (u64*)c->dkeys.p, dst);
+                   (const u32*)c->ghist.p, c->sk_ksegcap, c->sk_kfbits, sb - c->sk_kfbits, ts_log2, k, keys_out, dst);
         return P3_OK;
       }
       if (!xg) {
         if constexpr (NW == 2) {
           if (d16) {
             LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB << sb, 1024, lds, (const Rec16*)c->kpart.p, (const u32*)c->seg_off.p,
-                       (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
+                       (const u32*)c->ghist.p, sb, ts_log2, keys_out, dst, (u32)c->dbg_opt);
             return P3_OK;
           }
         }
         LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB << sb, 1024, lds, (const REC*)c->kpart.p,
-                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sb, ts_log2, (u64*)c->dkeys.p, dst,
+                   (const u32*)c->seg_off.p, (const u32*)c->ghist.p, sb, ts_log2, keys_out, dst,
                    (u32)c->dbg_opt);
         return P3_OK;
       }
@@ -277,13 +282,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         if constexpr (NW == 2) {
           if (d16) {
             LAUNCH_LDS(c, "k_kmer_dedup16", k_kmer_dedup16, P3_NB, 1024, lds, (const Rec16*)c->klpart.p, (const u32*)c->seg_off2.p,
-                       (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
+                       (const u32*)c->ghist2.p, 0u, ts_log2, keys_out, dst, (u32)c->dbg_opt);
             done16 = true;
           }
         }
         if (!done16)
           LAUNCH_LDS(c, "k_kmer_dedup", (k_kmer_dedup<NW>), P3_NB, 1024, lds, (const REC*)c->klpart.p,
-                     (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, (u64*)c->dkeys.p, dst, (u32)c->dbg_opt);
+                     (const u32*)c->seg_off2.p, (const u32*)c->ghist2.p, 0u, ts_log2, keys_out, dst, (u32)c->dbg_opt);
       }
       return P3_OK;
     };
@@ -355,9 +360,9 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     }
     if (use_dedup && c->kphase == 1 && !c->dall_cap) {
       // first chunk: the global deduplication needs the list, its partition, the second-level partition and the
-      // key output at once (about 4.5x the list).  When the lists of all chunks do not fit (config #4: 16-byte keys
+      // probe partition at once (about 3.5x the list; the key output reuses the list's buffer).  When the lists of all chunks do not fit (config #4: 16-byte keys
       // of 10 G bases) the chunks are collected in GROUPS of as many as do; below two, chunk by chunk as before
-      const double per_chunk = ((double)h[0] * 1.3 + (double)(1u << 16)) * 8 * NW * 4.5;
+      const double per_chunk = ((double)h[0] * 1.3 + (double)(1u << 16)) * 8 * NW * 3.5;
       size_t mem_free = 0, mem_total = 0;
       u32 fit = 0;
       if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess)
@@ -381,7 +386,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       c->ksbits_k = k;
       c->n_distinct_k = h[0];
       if (c->dall_n + h[0] > c->dall_cap) return fail(c, P3_ECAPACITY, "collected k-mer list full");
-      HIPCHK(c, hipMemcpyAsync((u64*)c->dall.p + c->dall_n * NW, c->dkeys.p, h[0] * 8 * NW, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync((u64*)c->dall.p + c->dall_n * NW, keys_out, h[0] * 8 * NW, hipMemcpyDeviceToDevice, c->stream));
       c->dall_n += h[0];
       c->bloom_mode = 3;
     } else if (use_dedup) {
@@ -422,13 +427,13 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)
 #define POS_SCATTER(MULTI, M32, SB)                                                                                            \
-  LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, MULTI, M32>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,     \
+  LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, MULTI, M32>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)keys_out,     \
              (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p, (const u64*)(st + 12), (u64)0, \
              st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), SB, ns)
             const bool m32 = m < (1ull << 32);
             if (rec16) {  // (one sweep, m < 2^26: 2-byte in-slice offsets)
               LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false, true, unsigned short>), P3_NWG, P3_PART_THREADS, lds_sc,
-                         (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p,
+                         (const u64*)keys_out, (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p,
                          (unsigned short*)c->ppart.p, (const u64*)(st + 12), (u64)0, st + 24,
                          (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), 0u, ns);
             } else if (sweeps > 1) {
@@ -442,10 +447,10 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
           } else {
             if (!c->spec && (rc = ensure(c, c->ppart, (n_pos + n_pos / 8 + 16ull * P3_NWG * P3_NB) * 4))) return rc;
             const u64 cap_records = c->ppart.bytes / 4;
-            LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)c->dkeys.p, (const u64*)dst, k,
+            LAUNCH(c, "k_pos_hist", (k_pos_hist<NW>), P3_NWG, P3_PART_THREADS, (const u64*)keys_out, (const u64*)dst, k,
                    mm, H, slice_log2, (u32*)c->ghist.p);
             if ((rc = do_scan(c, st + 12))) return rc;
-            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)c->dkeys.p,
+            LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)keys_out,
                        (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
                        (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
           }
@@ -462,7 +467,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         c->bloom_mode = 3;
       } else {
         HIPCHK(c, zero_bloom());
-        LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)c->dkeys.p, (const u64*)dst, k, mm, H,
+        LAUNCH(c, "k_bloom_insert", (k_bloom_insert<NW>), 4096, 256, (const u64*)keys_out, (const u64*)dst, k, mm, H,
                (u32*)c->bloom.p);
         c->bloom_mode = 2;
       }
