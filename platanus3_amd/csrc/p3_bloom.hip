@@ -426,22 +426,24 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             if ((rc = ensure(c, c->ppart, (u64)P3_NB * P3_NWG * segcap_p * 4))) return rc;
             if ((rc = fixed_segoff(c, segcap_p))) return rc;
             // (m < 2^32 -- BASELINE configs #2, #3, #5: the probe sequence in 32-bit arithmetic, p3_device.h:probe32_step)
-#define POS_SCATTER(MULTI, M32, SB)                                                                                            \
+#define POS_SCATTER(MULTI, M32, SB, HM)                                                                                          \
   LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, MULTI, M32>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)keys_out,     \
              (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p, (const u64*)(st + 12), (u64)0, \
-             st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), SB, ns)
+             st + 24, (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), SB, ns, HM)
             const bool m32 = m < (1ull << 32);
             if (rec16) {  // (one sweep, m < 2^26: 2-byte in-slice offsets)
               LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false, true, unsigned short>), P3_NWG, P3_PART_THREADS, lds_sc,
                          (const u64*)keys_out, (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p,
                          (unsigned short*)c->ppart.p, (const u64*)(st + 12), (u64)0, st + 24,
-                         (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), 0u, ns);
+                         (EstSeg{segcap_p, (u32*)c->ghist.p, st + 34}), 0u, ns, 0u);
             } else if (sweeps > 1) {
-              if (m32) POS_SCATTER(true, true, sbase);
-              else POS_SCATTER(true, false, sbase);
+              // (16-byte keys: the first sweep leaves h1, h2 in place of every key, the others read them -- k_pos_scatter)
+              const u32 hm = NW == 2 && c->hcache_opt != 1 ? (sbase == 0 ? 1u : 2u) : 0u;
+              if (m32) POS_SCATTER(true, true, sbase, hm);
+              else POS_SCATTER(true, false, sbase, hm);
             } else {
-              if (m32) POS_SCATTER(false, true, 0u);
-              else POS_SCATTER(false, false, 0u);
+              if (m32) POS_SCATTER(false, true, 0u, 0u);
+              else POS_SCATTER(false, false, 0u, 0u);
             }
 #undef POS_SCATTER
           } else {
@@ -452,7 +454,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
             if ((rc = do_scan(c, st + 12))) return rc;
             LAUNCH_LDS(c, "k_pos_scatter", (k_pos_scatter<NW, false>), P3_NWG, P3_PART_THREADS, lds_sc, (const u64*)keys_out,
                        (const u64*)dst, k, mm, H, slice_log2, (const u32*)c->seg_off.p, (u32*)c->ppart.p,
-                       (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns);
+                       (const u64*)(st + 12), cap_records, st + 24, (EstSeg{0, nullptr, nullptr}), 0u, ns, 0u);
           }
           if (c->n_ranks > 1 || bwords_padded != bwords) HIPCHK(c, zero_bloom());  // (the slices cover words below bwords)
           if (rec16)

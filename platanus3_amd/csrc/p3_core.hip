@@ -316,6 +316,9 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
     // forget what earlier passes over these reads learnt (sub-bucket splits, segment sizes, the single-synchronisation
     // replay): the next pass runs as the FIRST pass over new reads would.  bench.py times "cold" steps this way.
     forget_learnt(c, false);
+  } else if (n == "sweep_hashes") {
+    if (value < 0 || value > 1) return fail(c, P3_EBADARG, "sweep_hashes must be 0 (first sweep leaves h1, h2 for the others) or 1 (every sweep hashes)");
+    c->hcache_opt = (int)value;
   } else if (n == "kmer_slots") {
     if (value < 0 || value > 1) return fail(c, P3_EBADARG, "kmer_slots must be 0 (16-byte slots for 32 < k <= 63) or 1 (key + state word)");
     c->dedup16_opt = (int)value;

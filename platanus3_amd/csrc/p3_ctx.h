@@ -203,6 +203,7 @@ struct p3_ctx {
   int sk_dbg = 0;            // timing experiments (results are wrong when non-zero)
   int sk_waves_opt = 16;     // waves per workgroup of the run-record consumers (4..16)
   int sk_ts_log2_opt = 13;   // LDS slots (8 B) per sub-bucket table of the run-record kernels
+  int hcache_opt = 0;        // 1 = every probe sweep hashes its keys itself (tests)
   int dedup16_opt = 0;       // 1 = 16-byte k-mers always on the 20-byte-slot sets (tests)
   int probe16_opt = 0;       // 1 = never use 2-byte probe records (tests)
   int countq_opt = 0;        // 0 = count stage on 4-byte quotient slots where they apply (p3_kernels_countq.h), 1 = never

@@ -922,7 +922,10 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
                                                                  const u32* __restrict__ seg_off, PREC* __restrict__ out,
                                                                  const u64* __restrict__ totals, u64 cap,
                                                                  u64* __restrict__ cap_flag, EstSeg est, u32 slice_base,
-                                                                 u32 slice_cnt) {
+                                                                 u32 slice_cnt, u32 hmode) {
+  // hmode (16-byte keys, several sweeps): every sweep needs (h1, h2) of every key, and the two _Hash_bytes passes are most
+  // of what a sweep spends on a key it keeps few probes of -- so the FIRST sweep (1) writes h1, h2 over the key, in place
+  // (nothing reads the distinct keys after the probes), and the others (2) read them back instead of hashing.
   if (!est.segcap && totals[1] > cap) {  // exact mode: the padded total must fit the buffer
     if (blockIdx.x == 0 && threadIdx.x == 0) *cap_flag = 1;
     return;
@@ -947,7 +950,17 @@ static __global__ void __launch_bounds__(P3_PART_THREADS) k_pos_scatter(const u6
     if (active) {
       const u64 lo = keys[i * NW], hi = (NW == 2) ? keys[i * NW + 1] : 0;
       u64 h1, h2;
-      double_hash_key<NW>(lo, hi, k, h1, h2);
+      if (NW == 2 && MULTI && hmode == 2u) {
+        h1 = lo;
+        h2 = hi;
+      } else {
+        double_hash_key<NW>(lo, hi, k, h1, h2);
+        if (NW == 2 && MULTI && hmode == 1u) {
+          u64* kw = const_cast<u64*>(keys);
+          kw[i * NW] = h1;
+          kw[i * NW + 1] = h2;
+        }
+      }
       if constexpr (M32) pr = probe32_begin(h1, h2, mm);
       else pr = probe_begin(h1, h2, mm);
     }

@@ -1187,3 +1187,25 @@ def test_sixteen_byte_kmer_sets_on_both_slot_layouts(oracle, k):
                 assert used16 == (slots == 0 and k <= 63) and used20 == (not used16)
             finally:
                 c.close()
+
+
+@pytest.mark.gpu
+def test_probe_sweeps_of_sixteen_byte_keys_share_their_hashes(oracle):
+    """A vector of more than 2^32 bits is built in several sweeps over the distinct keys; with 16-byte keys the first
+    sweep leaves (h1, h2) in place of every key and the others read them back instead of hashing again (k_pos_scatter,
+    hmode).  Same vector as the oracle, and as with every sweep hashing for itself (sweep_hashes=1)."""
+    b, o = synth.reads(seed=91, total_reads=300, read_len=2000, sub_rate_ppm=10000)
+    k, H = 45, 5
+    m = (1 << 32) + 12345
+    c = capi.Context(0)
+    try:
+        c.set_profiling(True)
+        words, _ = run_and_compare(c, oracle, (b, o), k, m, H)
+        assert c.kernel_stats()["k_pos_scatter"]["launches"] >= 2  # (two sweeps of <= 1024 buckets of four LDS slices)
+        c.run_pass(k, m, H)
+        assert np.array_equal(words, c.export_bloom())
+        c.set_option("sweep_hashes", 1)
+        c.run_pass(k, m, H)
+        assert np.array_equal(words, c.export_bloom())
+    finally:
+        c.close()
