@@ -109,8 +109,20 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 2x -- fewer bytes to
  *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
  *                 both forms record by record, so ranks need not agree.
+ *   "count_slots" 0 (default) = the count stage tries 4-byte quotient slots first wherever its records are 8-byte
+ *                 position records (tables of twice the keys; what such a table cannot hold -- a key with >= 1024
+ *                 instances, a crowded table -- is flagged and counted on 8-byte slots by the launch behind it, same
+ *                 results); 1 = 8-byte slots only (tests).
+ *   "kmer_slots"  0 (default) = k-mers of 33 ... 63 bases are deduplicated on 16-byte slots (the claim protocol in the
+ *                 spare bits of the high key word); 1 = key + state word, as k = 64 always is (tests).
+ *   "probe_records" 0 (default) = 2-byte probe records where the in-slice offsets fit them (vectors up to 2^26 bits);
+ *                 1 = 4-byte records only (tests).
+ *   "sweep_hashes" vectors built in several sweeps, 16-byte keys: 0 (default) = the first sweep leaves (h1, h2) in place
+ *                 of every key for the others; 1 = every sweep hashes its keys itself (tests).
  * p3_get_info reads back "count_mode"/"bloom_mode" (paths the last pass used), "sbits", "ksbits",
- * "rs_log2", "distinct_kmers", "est_fallbacks", "est_level", "kmer_groups", "mr_aggregated", "mr_send_records", "mr_distinct_estimate". */
+ * "rs_log2", "distinct_kmers", "est_fallbacks", "est_level", "kmer_groups", "mr_aggregated", "mr_send_records",
+ * "mr_distinct_estimate", "quotient_tables" / "quotient_redone" (tables of the last count on quotient slots / of those,
+ * left to the 8-byte kernel), "probe_record_bytes", "pass_replayed". */
 int p3_set_option(p3_ctx* ctx, const char* name, int64_t value);
 int p3_get_info(p3_ctx* ctx, const char* name, int64_t* value);
 
