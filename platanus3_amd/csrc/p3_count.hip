@@ -330,9 +330,13 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
     // instead, so that every cell is read once.  An overflow of the estimate clears est_ok and lands in the exact
     // form below.
     u32 xg = 0, sb_int = sbits;
-    if (c->split_opt >= 2) xg = (u32)c->split_opt - 1;
-    else if (c->split_opt != 1 && sbits >= 3) xg = sbits;
-    if (xg) sb_int = 0;
+    if (c->split_opt >= 2) {
+      xg = (u32)c->split_opt - 1;  // (tests: a forced depth; sub-buckets come on top of it when its cells still overflow --
+                                   // found by the randomised sweep: 64-slot tables, 8 ranks, the split forced to 4 groups)
+    } else if (c->split_opt != 1 && sbits >= 3) {
+      xg = sbits;
+      sb_int = 0;
+    }
     u32 lg = 0;
     while ((1u << lg) < c->n_ranks) lg++;
     if (lg + xg <= P3_PBITS) {
