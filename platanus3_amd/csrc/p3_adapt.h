@@ -53,6 +53,11 @@ struct P3Adapt {
     else est_ok = false;
   }
   void collection_overflowed() { kcollect_ok = false; }
+  // what a count on 4-byte quotient slots left to the 8-byte kernel: an eighth of its tables or more -- crowded tables or
+  // heavy keys everywhere -- and the quotient slots are given up for these reads
+  void quotient_tables_redone(uint64_t tables, uint64_t redone) {
+    if (tables && redone * 8 > tables) q_ok = false;
+  }
   void run_records_failed(bool retry_larger) {
     if (retry_larger && sk_boost == 0) sk_boost = 1;
     else sk_ok = false;

@@ -313,7 +313,7 @@ static int launch_countq(p3_ctx* c, bool tagged, u32 nq, size_t lds, const void*
 
 void quotient_outcome(p3_ctx* c, u64 redone) {
   c->q_redone = redone;
-  if (c->q_tables && redone * 8 > c->q_tables) c->ad.q_ok = false;
+  c->ad.quotient_tables_redone(c->q_tables, redone);
 }
 
 // whether the quotient-slot count may be tried on these reads (it is given up for them once an eighth of its tables had

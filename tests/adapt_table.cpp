@@ -2,7 +2,8 @@
 // the state it must end in.  Events: E = estimate overflowed (memory allows level 2), e = the same with level 1 as the
 // top, x = estimate overflowed with boosting switched off (tests), C = collection overflowed, S = run records failed
 // (retry larger), s = run records failed (no retry), H = a pass completed (hints valid), D = drop_hints, N = new reads,
-// P = the probe partition overflowed (it keeps a level of its own: probe_boost).
+// P = the probe partition overflowed (it keeps a level of its own: probe_boost), q = a count on quotient slots left 3 of
+// its 1000 tables to the 8-byte kernel (nothing changes), Q = 200 of 1000 (the quotient slots are given up for the reads).
 #include <cstdio>
 #include <cstring>
 
@@ -16,6 +17,7 @@ struct Row {
   bool hint_valid;
   unsigned long long fallbacks;
   unsigned probe_boost = 0;
+  bool q_ok = true;
 };
 
 static const Row table[] = {
@@ -43,6 +45,11 @@ static const Row table[] = {
     {"EPP",     1,    true,  true,  true,  true,  0,  false, 3, 2},
     {"PPP",     0,    false, true,  true,  true,  0,  false, 3, 2},  // ... and ends in exact offsets like the others
     {"PPD",     0,    true,  true,  true,  true,  0,  false, 2, 0},
+    {"q",       0,    true,  true,  true,  true,  0,  false, 0, 0, true},   // a few heavy keys: the launch behind counts them
+    {"qQ",      0,    true,  true,  true,  true,  0,  false, 0, 0, false},  // an eighth of the tables and more: 8-byte slots only
+    {"QE",      1,    true,  true,  true,  true,  0,  false, 1, 0, false},  // (independent of the estimates)
+    {"QD",      0,    true,  true,  true,  true,  0,  false, 0, 0, true},   // drop_hints / new reads: tried again
+    {"QN",      0,    true,  true,  true,  true,  0,  false, 0, 0, true},
 };
 
 int main() {
@@ -58,6 +65,8 @@ int main() {
         case 'x': a.estimate_overflowed(2, false); break;
         case 'C': a.collection_overflowed(); break;
         case 'P': a.probes_overflowed(); break;
+        case 'q': a.quotient_tables_redone(1000, 3); break;
+        case 'Q': a.quotient_tables_redone(1000, 200); break;
         case 'S': a.run_records_failed(true); break;
         case 's': a.run_records_failed(false); break;
         case 'H': a.hint_valid = true; break;
@@ -68,7 +77,7 @@ int main() {
     }
     const bool ok = a.est_boost == r.est_boost && a.est_ok == r.est_ok && a.chunk_ok == r.chunk_ok &&
                     a.kcollect_ok == r.kcollect_ok && a.sk_ok == r.sk_ok && a.sk_boost == r.sk_boost &&
-                    a.hint_valid == r.hint_valid && a.fallbacks == r.fallbacks && a.probe_boost == r.probe_boost &&
+                    a.hint_valid == r.hint_valid && a.fallbacks == r.fallbacks && a.probe_boost == r.probe_boost && a.q_ok == r.q_ok &&
                     a.distinct_cap == (saw_new ? 0ull : 77ull);  // (only new reads forget the output size)
     if (!ok) {
       std::printf("row \"%s\": boost %u est %d chunk %d collect %d sk %d skb %u hint %d fallbacks %llu cap %llu\n", r.events,
