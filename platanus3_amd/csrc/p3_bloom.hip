@@ -251,7 +251,11 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       int r2;
       const u32 groups = 1u << xg, rows = P3_NB >> xg;
       // (kphase 2: the lumps of the tiled key scatter come through segment by segment)
-      const u32 segcap2 = segcap_for(c, krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? c->chunks * 64u : 0u);
+      // (kphase 2: the lumps of the tiled key scatter sit in the level-1 segments; the cell bits of the keys inside a lump are
+      // as good as random, so the level-2 segments need a tile of slack, not a tile per chunk -- and the bucket reader walks a
+      // cell's whole capacity range: at 16 chunks the old margin of 1,024 records on segments of ~50 made every launch of the
+      // collected list's dedup cost ~500 us whatever it held, config #4: 151 of 258 ms)
+      const u32 segcap2 = segcap_for(c, krecords / ((double)groups * P3_NB * P3_NWG)) + (c->kphase == 2 ? 16u * (u32)c->kmargin2_opt : 0u);
       const bool var = var_caps_on(c);  // per-cell capacities from a sample, as in count_split
       const u64 cap_records = (u64)P3_NB * P3_NWG * segcap2 + (var ? (u64)P3_NB * P3_NWG * segcap2 / 4 : 0);
       if ((r2 = ensure(c, c->klpart, cap_records * sizeof(REC)))) return r2;
@@ -320,6 +324,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         kxg = 1;
         while (kxg < 10 && (c->dall_n >> kxg) / P3_NB > ((u64)4 << ts_log2)) kxg++;
         if (c->kxg_all_epoch == c->reads_epoch && c->kxg_all_k == k && c->kxg_all > kxg) kxg = c->kxg_all;
+        if (c->kload_all_opt > 1 && (u32)c->kload_all_opt > kxg) kxg = (u32)c->kload_all_opt;  // (experiments: a forced depth)
       }
       if (c->ksplit_opt >= 2 && est) {  // tests: force the split form (it only exists with estimated capacities)
         kxg = (u32)c->ksplit_opt - 1;
@@ -352,7 +357,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
       // k_kmer_dedup 45.9 -> 33.8 ms per pass; 16 M reads 3 -> 4, 12.9 -> 11.3 ms; one level deeper still and the fixed
       // cost of 2^split more launches (clearing and scanning 1024 sets, ~50 us) wins again.  The collected list of all
       // chunks (kphase 2) stays at its smallest split: one launch series over few records, deepening it only cost.
-      if (use_dedup && kxg && c->kphase != 2 && !c->kpart_sk && !c->ksplit_opt) {
+      if (use_dedup && kxg && (c->kphase != 2 || c->kload_all_opt) && !c->kpart_sk && !c->ksplit_opt) {
         const u32 pct = c->kload_pct_opt ? (u32)c->kload_pct_opt : p3_ctx::KLOAD_PCT;
         const u64 per_split = ((u64)P3_NB << ts_log2) * pct / 100;  // distinct keys one round's 1024 sets should hold
         while (kxg_next < 8 && h[0] > (per_split << kxg_next)) kxg_next++;
@@ -396,6 +401,7 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
         c->ksbits_epoch = c->reads_epoch;
         c->ksbits_k = k;
       } else {
+        if (getenv("P3_TRACE_CHUNKS")) fprintf(stderr, "[p3] collected list: %llu keys, %llu distinct, split %u (next %u), slots 2^%u\n", (unsigned long long)c->dall_n, (unsigned long long)h[0], kxg, kxg_next, ts_log2);
         c->kxg_all = std::max(kxg, kxg_next);
         c->kxg_all_epoch = c->reads_epoch;
         c->kxg_all_k = k;

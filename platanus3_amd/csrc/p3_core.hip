@@ -319,6 +319,11 @@ int p3_set_option(p3_ctx* c, const char* name, int64_t value) {
   } else if (n == "sweep_hashes") {
     if (value < 0 || value > 1) return fail(c, P3_EBADARG, "sweep_hashes must be 0 (first sweep leaves h1, h2 for the others) or 1 (every sweep hashes)");
     c->hcache_opt = (int)value;
+  } else if (n == "kmer_margin2") {
+    if (value < 0 || value > 4096) return fail(c, P3_EBADARG, "kmer_margin2 must be in [0,4096]");
+    c->kmargin2_opt = (int)value;
+  } else if (n == "kmer_load_all") {
+    c->kload_all_opt = (int)value;  // (0 / 1, or a forced split depth of the collected list: experiments)
   } else if (n == "kmer_slots") {
     if (value < 0 || value > 1) return fail(c, P3_EBADARG, "kmer_slots must be 0 (16-byte slots for 32 < k <= 63) or 1 (key + state word)");
     c->dedup16_opt = (int)value;

@@ -132,6 +132,8 @@ struct p3_ctx {
   u64 chunk_w0[17] = {0};
   int ksplit_opt = 0;         // 0 = auto, x+1 (2..11) = force x split bits for the k-mer records (tests)
   static constexpr u32 KLOAD_PCT = 50;
+  int kmargin2_opt = 1;       // collected list, level-2 segments: tiles (16 records) of slack on top of the estimate
+  int kload_all_opt = 0;      // 1 = the collected list's split aims at kmer_load_pct as well (experiment)
   int kload_pct_opt = 0;      // split form: distinct keys per set slot aimed at, in percent (0 = KLOAD_PCT, 100 = smallest split that fits)
   u32 kxg_all = 0, kxg_all_k = 0;  // split bits learnt for the collected list of all chunks (kphase 2)
   u64 kxg_all_epoch = ~0ull;
