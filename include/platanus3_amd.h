@@ -107,8 +107,9 @@ int p3_set_profile_filter(p3_ctx* ctx, const char* kernel_name);
  *   "mr_aggregate" multi-rank, return-path gate: 1 (default) = p3_mr_count_partition replaces this rank's 21-mer
  *                 records by ONE record per distinct local key (a position for a key seen once, else bit 63 + the
  *                 local count) when a sampled estimate says the rank's reads repeat their keys >= 2x -- fewer bytes to
- *                 exchange and to count at the owner; 0 = never (raw instance records); 2 = always.  Owners accept
- *                 both forms record by record, so ranks need not agree.
+ *                 exchange and to count at the owner -- and, in p3_mr_run_pass, when some rank of the job lives on
+ *                 another GPU (several ranks sharing ONE GPU exchange by device copies: nothing to save); 0 = never
+ *                 (raw instance records); 2 = always.  Owners accept both forms record by record, so ranks need not agree.
  *   "count_slots" 0 (default) = the count stage tries 4-byte quotient slots first wherever its records are 8-byte
  *                 position records (tables of twice the keys; what such a table cannot hold -- a key with >= 1024
  *                 instances, a crowded table -- is flagged and counted on 8-byte slots by the launch behind it, same

@@ -107,6 +107,7 @@ struct p3_ctx {
   bool protocol = false;  // p3_mr_config was called: blobs must be contiguous, so segment offsets stay exact
   bool reparted = false;  // the received records have been split into 1024 local cells (n_ranks > 1)
   bool rx_weighted = false;  // received records may be pre-aggregated (bit 63 = count form): see k_part_count
+  bool agg_links = true;  // some of this rank's records leave the GPU (p3_mr_run_pass: false when all ranks share it)
   int agg_opt = 1;
   bool agg = false;          // this rank's send partition is pre-aggregated (apart)
   DevBuf apart;

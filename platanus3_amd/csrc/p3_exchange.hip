@@ -714,6 +714,10 @@ static int run_pass_steps(p3_ctx* c, p3_comm* cm, uint32_t k, uint64_t m_bits, u
     if ((rc = (expr))) return fail(c, rc, "%s", cm->err.c_str()); \
   } while (0)
   // ---- count: local partition, then blobs + descriptors to the bucket owners -------------------------------------
+  // (the sender-side aggregation trades ~3 ms of kernels for bytes off the links: when every rank of the job is a member
+  // of this process's group -- several protocol ranks on ONE GPU, no outer communicator -- nothing crosses a link and the
+  // default leaves the records raw; "mr_aggregate" = 2 still forces it)
+  c->agg_links = !(cm->group && cm->group->W == 1);
   if ((rc = p3_mr_count_partition(c))) return rc;
   p3_mr_send_layout lay;
   if ((rc = p3_mr_count_send_layout(c, &lay))) return rc;

@@ -45,7 +45,7 @@ int p3_mr_count_partition(p3_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->cstats.n_windows = nwin;
   c->agg = false;
-  if (c->n_ranks > 1 && c->agg_opt) {
+  if (c->n_ranks > 1 && c->agg_opt && (c->agg_opt == 2 || c->agg_links)) {
     if ((rc = agg_local(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
