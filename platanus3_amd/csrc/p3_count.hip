@@ -120,13 +120,17 @@ u64 wg_window_bound(const p3_ctx* c) {
   return per * 32;
 }
 
-// workgroups of the hist/scatter kernels that actually receive stream words (the shares are multiples of 1024 words,
-// so a small input keeps only a few of the 256 busy -- and their segments are that much longer)
+// workgroups of the hist/scatter kernels that receive stream words, counted in shares of the BUSIEST one (the shares are
+// multiples of 1024 words, so a small input keeps only a few of the 256 busy -- and their segments are that much
+// longer): windows / (buckets x this) is the mean segment length of the workgroup with a full share.  (It used to count
+// the workgroups that get any word at all: 1,028 words = one full share + 4 words came out as 2, every segment of the
+// full share was sized at half its mean -- and under forced position chunks a last chunk of 1,022 words, counted as 1,
+// needed twice the region the first chunk had laid out for all of them: found by the randomised sweep at shifted seeds.)
 double active_wgs(u64 n_words) {
   u64 per = (n_words + P3_NWG - 1) / P3_NWG;
   per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
-  const u64 a = per ? (n_words + per - 1) / per : 1;
-  return (double)(a ? a : 1);
+  if (!per || !n_words) return 1.0;
+  return (double)n_words / (double)(per < n_words ? per : n_words);
 }
 
 // Fixed-stride segment offsets (entry i = i * segcap).  A pass uses four different strides (count, return path, k-mers,
@@ -183,7 +187,11 @@ int part_local(p3_ctx* c, bool with_pos) {
   if ((rc = ensure(c, c->seg_off, (size_t)P3_NB * P3_NWG * 4))) return rc;
   if ((rc = ensure(c, c->bucket_count, (size_t)P3_NB * 4))) return rc;
   if (with_pos) {
-    if ((rc = ensure(c, c->part8, (est ? (u64)P3_NB * P3_NWG * segcap : max_records) * 8))) return rc;
+    const u64 need8 = (est ? (u64)P3_NB * P3_NWG * segcap : max_records) * 8;
+    // (position chunks: part8 is a window of the chunks' common buffer, laid out for the largest chunk -- never regrown here)
+    if (c->chunks > 1 && c->part8.p && need8 > c->part8.bytes)
+      return fail(c, P3_ECAPACITY, "position chunk: its partition needs %llu bytes, the chunks' regions hold %zu", (unsigned long long)need8, c->part8.bytes);
+    if ((rc = ensure(c, c->part8, need8))) return rc;
   } else {
     if ((rc = ensure(c, c->part, max_records * 4))) return rc;
   }

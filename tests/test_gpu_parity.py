@@ -889,6 +889,14 @@ def test_random_configurations(oracle, seed):
             opts["est_boost"] = 0
         if (seed + case) % 3 == 0:  # (not drawn from rng: the cases of the sweep stay the ones they were)
             opts["kmer_load_pct"] = (5, 20, 100)[(seed * 7 + case) % 3]
+        for name in [x for x in os.environ.get("P3_FUZZ_DROP", "").split(",") if x]:  # (bisecting a failing case by its options)
+            opts.pop(name, None)
+        for kv in [x for x in os.environ.get("P3_FUZZ_SET", "").split(",") if x]:
+            opts[kv.split("=")[0]] = int(kv.split("=")[1])
+        if os.environ.get("P3_FUZZ_ONLY_CASE") and int(os.environ["P3_FUZZ_ONLY_CASE"]) != case:
+            continue
+        if os.environ.get("P3_FUZZ_VERBOSE"):
+            print("seed %d case %d: k=%d m=%d H=%d reads=%d bases=%d opts=%r" % (seed, case, k, m, H, o.size - 1, b.size, opts), flush=True)
         c = capi.Context(0)
         try:
             for name, v in opts.items():
