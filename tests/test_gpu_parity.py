@@ -1223,3 +1223,25 @@ def test_probe_sweeps_of_sixteen_byte_keys_share_their_hashes(oracle):
         assert np.array_equal(words, c.export_bloom())
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_forced_chunks_of_one_workgroup_share_each(oracle):
+    """8,218 stream words in eight forced position chunks: seven of 1,028 words (one full workgroup share of 1,024 + 4
+    words for a second workgroup) and a last one of 1,022 (one share).  The segment estimates used to count the
+    workgroups that get ANY word -- the last chunk then needed twice the region laid out for the first, and the partition
+    step regrew what was a window of the chunks' common buffer (memory fault; found by the randomised sweep at
+    P3_FUZZ_OFFSET=1200000, seed 17 case 2).  Same results as the oracle, whatever level the estimates end at."""
+    b, o = synth.reads(seed=568349210, total_reads=2922, read_len=90, sub_rate_ppm=30000)
+    k, m, H = 59, 1 << 20, 5
+    c = capi.Context(0)
+    try:
+        c.set_option("chunks", 8)
+        run_and_compare(c, oracle, (b, o), k, m, H)
+        assert c.get_info("chunks") == 8
+        c.run_pass(k, m, H)
+        ekeys, ecounts = oracle.count_short((b, o), min_len=k)
+        keys, counts = c.export_counts()
+        assert np.array_equal(keys, ekeys) and np.array_equal(counts, ecounts)
+    finally:
+        c.close()
