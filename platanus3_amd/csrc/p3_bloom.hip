@@ -225,7 +225,8 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
     const double krecords = c->kphase == 2 ? (double)c->dall_n * 1.02
                                            : mean_k * (double)P3_NB * active_wgs(c->n_words);  // estimate of the passing k-mers
     auto dedup_once = [&](u32 sb, u32 xg) -> int {
-      HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
+      // (a replayed pass: part_local zeroed the whole statistics block and nothing has written these words since)
+      if (!c->spec) HIPCHK(c, hipMemsetAsync(dst, 0, 9 * 8, c->stream));
       if (c->kpart_sk) {
         const u32 nwaves = (u32)c->sk_waves_opt;
         const size_t lds_sk = ((size_t)8 << ts_log2) + nwaves * SK_DWAVE_LDS + P3_NWG * 4 + 64;

@@ -299,7 +299,7 @@ int set_k2ext(p3_ctx* c, u64 out_cap, const void* sroff, u32 n) {
   return P3_OK;
 }
 
-// quotient-slot count of nq tables (p3_kernels_countq.h); the k_part_count launch behind it finds the flags through dstats[33]
+// quotient-slot count of nq tables (p3_kernels_countq.h); the k_part_count launch behind it gets c->redo, the table of flags
 static int launch_countq(p3_ctx* c, bool tagged, u32 nq, size_t lds, const void* part, const void* seg, const void* hist, u32 first_pb,
                          u32 xbits, u32 sbits_q, u32 n_src) {
   int rc;
@@ -401,32 +401,30 @@ int count_owned(p3_ctx* c, u32 sbits, bool* overflowed, u64* max_solid_sb) {
       LAUNCH_K2(true, nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
+                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (const u32*)nullptr,
                  k2_mode(c));
     } else {
       // one reader per bucket on 4-byte quotient slots (p3_kernels_countq.h): tables of twice the keys, so one split
       // bit less; what such a table cannot hold (a key with >= 1024 instances, a crowded table) is flagged and
       // counted by the launch behind it, which returns at once for everything else
       const bool q = countq_on(c, ts_log2) && c->n_ranks == 1 && xbits == 0 && sbits >= 1 && !(k2_mode(c) & P3_K2_WEIGHTED);
-      if (q) {
-        if ((rc = launch_countq(c, false, rows << (sbits - 1), lds, kpart, kseg, khist, c->rank * rows, 0u, sbits - 1, 1u))) return rc;
-        c->k2ext_h[1] = (u64)(uintptr_t)c->redo.p;
-        HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
-      }
+      if (q && (rc = launch_countq(c, false, rows << (sbits - 1), lds, kpart, kseg, khist, c->rank * rows, 0u, sbits - 1, 1u))) return rc;
       LAUNCH_K2(false, nsb, 1024, lds, (const u64*)kpart,
                  (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                  c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (u32)c->dbg_opt,
+                 (u64*)c->tpos.p, (u32*)c->singles.p, (u64*)c->sing_cursor.p, (const u32*)(q ? c->redo.p : nullptr),
                  k2_mode(c));
-      if (q) HIPCHK(c, hipMemsetAsync(st + 33, 0, 8, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    // (a replayed pass sizes the return path from last pass's count and reads this one at its single synchronisation: a
+    // device-to-host copy into pageable memory here would stall the host until the count kernel is done, and every launch
+    // behind it would then reach the GPU late)
+    if (!c->spec) HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
   } else {
     const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VALID_CAP + 16 * P3_WQ_CAP * 4;
     LAUNCH_LDS(c, "k_part_count", (k_part_count<false>), nsb, 1024, lds, (const u32*)kpart,
                (const u32*)kseg, (const u32*)khist, (const u64*)c->rx_roff.p, c->n_ranks, rows,
                c->rank * rows, xbits, sbits, ts_log2, (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st,
-               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, 0u);
+               (u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (const u32*)nullptr, 0u);
   }
   c->sbits = sbits;
   c->ccounts_u32 = true;
@@ -553,9 +551,6 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
   }
   const size_t lds_split = ((size_t)P3_STAGE_WORDS + 2 * P3_NB + 4) * 4;
   const size_t lds = ((size_t)2 << ts_log2) * 4 + 576 + P3_VCAP_POS + 16 * P3_WQ_CAP_POS * 8;
-  if (q) {
-    c->k2ext_h[1] = 0;  // (set once the flag buffer exists: after the first quotient launch)
-  }
   for (u32 g = 0; g < groups; g++) {
     if (var) {
       LAUNCH(c, "k_cell_sample", (k_cell_sample<u64, 0>), P3_NWG, P3_PART_THREADS, (const u64*)c->rx_part, (const u32*)c->rx_segoff,
@@ -573,27 +568,21 @@ int count_split(p3_ctx* c, u32 xg, u32 sbits, bool* overflowed, u64* max_solid_s
       if ((rc = launch_countq(c, n_src > 1, (u32)P3_NB << sbits_q, lds, c->lpart.p, c->seg_off2.p, c->ghist2.p, first_pb + g * rows, xbits,
                               sbits_q, n_src)))
         return rc;
-      const u64 flags = (u64)(uintptr_t)c->redo.p;
-      if (c->k2ext_h[1] != flags) {
-        c->k2ext_h[1] = flags;
-        HIPCHK(c, hipMemcpyAsync(st + 33, &c->k2ext_h[1], 8, hipMemcpyHostToDevice, c->stream));
-      }
     }
     const u32 sbits_run = sbits_k;
     if (n_src > 1) {  // (xbits >= log2 n_src by construction)
       LAUNCH_K2(true, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits_run, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
+                 (u64*)c->sing_cursor.p, (const u32*)(q ? c->redo.p : nullptr), k2_mode(c));
     } else {
       LAUNCH_K2(false, nsb, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                  (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, n_src, rows, first_pb + g * rows, xbits, sbits_run, ts_log2,
                  (u64*)c->ckeys.p, (u32*)c->ccounts.p, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)c->singles.p,
-                 (u64*)c->sing_cursor.p, (u32)c->dbg_opt, k2_mode(c));
+                 (u64*)c->sing_cursor.p, (const u32*)(q ? c->redo.p : nullptr), k2_mode(c));
     }
   }
-  if (q) HIPCHK(c, hipMemsetAsync(st + 33, 0, 8, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
+  if (!c->spec) HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8 * n_src, hipMemcpyDeviceToHost, c->stream));
   c->sbits = sbits;
   c->ccounts_u32 = true;
   if (c->spec) {
@@ -757,7 +746,7 @@ int agg_local(p3_ctx* c) {
     LAUNCH_LDS(c, "k_part_count", (k_part_count<true, false>), sample_buckets << sample_sbits, 1024, lds, (const u64*)c->part8.p,
                (const u32*)c->seg_off.p, (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u,
                sample_sbits, ts_log2, (u64*)nullptr, (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p,
-               (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+               (u32*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32)P3_K2_AGG_OUT);
     HIPCHK(c, hipMemcpyAsync(h, st, sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const u64 distinct_est = h[0] * (P3_NB / sample_buckets) + 1;
@@ -801,7 +790,7 @@ int agg_local(p3_ctx* c) {
         LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), P3_NB, 1024, lds, (const u64*)c->lpart.p, (const u32*)c->seg_off2.p,
                    (const u32*)c->ghist2.p, (const u64*)c->rx_roff.p, 1u, rows, g * rows, sbits, 0u, ts_log2, (u64*)nullptr,
                    (u32*)nullptr, (uint4*)c->sb_info.p + (size_t)g * P3_NB, st, (u64*)c->tpos.p + (((size_t)g * P3_NB) << ts_log2),
-                   (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt, (u32)P3_K2_AGG_OUT);
+                   (u32*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32)P3_K2_AGG_OUT);
       }
       u64 h2[P3_NSTAT];
       HIPCHK(c, hipMemcpyAsync(h2, st, sizeof h2, hipMemcpyDeviceToHost, c->stream));
@@ -817,7 +806,7 @@ int agg_local(p3_ctx* c) {
     if (!split_done) {
       LAUNCH_LDS(c, "k_part_count", (k_part_count<true>), nsb, 1024, lds, (const u64*)c->part8.p, (const u32*)c->seg_off.p,
                  (const u32*)c->ghist.p, (const u64*)c->rx_roff.p, 1u, (u32)P3_NB, 0u, 0u, sbits, ts_log2, (u64*)nullptr,
-                 (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (u32)c->dbg_opt,
+                 (u32*)nullptr, (uint4*)c->sb_info.p, st, (u64*)c->tpos.p, (u32*)nullptr, (u64*)nullptr, (const u32*)nullptr,
                  (u32)P3_K2_AGG_OUT);
       HIPCHK(c, hipMemcpyAsync(h, st, 5 * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));

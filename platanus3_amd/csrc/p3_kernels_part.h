@@ -308,12 +308,12 @@ static __global__ void __launch_bounds__(1024) k_part_count(const typename std::
                                                      u32* __restrict__ out_counts, uint4* __restrict__ sb_info,
                                                      u64* __restrict__ gstats, u64* __restrict__ tpairs,
                                                      u32* __restrict__ singles,
-                                                     u64* __restrict__ sing_cursor, u32 dbg, u32 mode) {
+                                                     u64* __restrict__ sing_cursor, const u32* __restrict__ redo, u32 mode) {
   typedef typename std::conditional<POS, u64, u32>::type REC;
   if constexpr (POS) {
-    // launched behind k_part_countq (p3_kernels_countq.h): gstats[33] = its table of flags, one per PAIR of this
-    // kernel's sub-buckets; only the flagged ones are counted here
-    const u32* redo = reinterpret_cast<const u32*>(gstats[33]);
+    // launched behind k_part_countq (p3_kernels_countq.h): redo = its table of flags, one per PAIR of this kernel's
+    // sub-buckets; only the flagged ones are counted here.  (A kernel argument: the pointer used to travel through a word
+    // of the statistics block -- an 8-byte host-to-device copy before and a memset after every such launch.)
     if (redo) {
       const u32 nsub0 = 1u << sbits;
       const u32 grp0 = blockIdx.x / (8u * nsub0), rr0 = blockIdx.x % (8u * nsub0);
