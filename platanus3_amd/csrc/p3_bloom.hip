@@ -1,5 +1,6 @@
 // p3_bloom.hip -- G1/G2/B1/B2 MakeBF (src/MakeBloomFilter.cpp:24-89, src/bloomfilter.cpp): gate, k-mer partition + dedup, probes, LDS
 // slices, seeds and the seed set; p3_run_pass (gfx950 only).
+#include <cstring>
 #include "p3_ctx.h"
 
 using namespace p3i;
@@ -504,11 +505,17 @@ int do_bloom_t(p3_ctx* c, u32 k, u64 m, u32 H) {
   HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
   u64 hall[P3_NSTAT];
   u32 unk[4] = {0, 0, 0, 0};
-  HIPCHK(c, hipMemcpyAsync(hall, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
-  if (c->spec && c->part_pos)
-    HIPCHK(c, hipMemcpyAsync(c->sing_count, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
+  // (into pinned memory where there is some: copies into pageable memory block the host one after the other)
+  u64* const hdst = c->pin_host ? c->pin_host : hall;
+  u64* const sdst = c->pin_host ? c->pin_host + P3_NSTAT : c->sing_count;
+  HIPCHK(c, hipMemcpyAsync(hdst, st, sizeof hall, hipMemcpyDeviceToHost, c->stream));
+  if (c->spec && c->part_pos) HIPCHK(c, hipMemcpyAsync(sdst, c->sing_cursor.p, 8, hipMemcpyDeviceToHost, c->stream));
   if (c->part_sk && c->unk_flag.p) HIPCHK(c, hipMemcpyAsync(unk, c->unk_flag.p, 16, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->pin_host) {
+    std::memcpy(hall, hdst, sizeof hall);
+    if (c->spec && c->part_pos) c->sing_count[0] = sdst[0];
+  }
   if ((c->part_sk && c->spec && (unk[0] || hall[26] || hall[3] == 2)) || (c->kpart_sk && hall[28])) {
     // run records did not fit (checked here for a single-synchronisation pass; the k-mer records in any case)
     sk_failed(c, !unk[0] && hall[3] != 2);

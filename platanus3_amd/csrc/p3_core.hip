@@ -212,6 +212,10 @@ int p3_create(p3_ctx** out, int device_ordinal) {
       delete c;
       return P3_EHIP;
     }
+  if (hipHostMalloc((void**)&c->pin_host, 4096, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    c->pin_host = nullptr;  // (pageable fallback: the copies then block one after the other, results are the same)
+  }
   *out = c;
   return P3_OK;
 }
@@ -239,6 +243,7 @@ int p3_destroy(p3_ctx* c) {
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->pin_host) (void)hipHostFree(c->pin_host);
   delete c;
   return P3_OK;
 }

@@ -225,6 +225,8 @@ struct p3_ctx {
   p3_bloom_stats bstats{};
 
   hipEvent_t ev[8] = {};
+  u64* pin_host = nullptr;  // 4 KiB of pinned host memory: the end-of-pass reads (statistics block, single-instance count)
+                            // land here, so both copies are queued behind the last kernel and ONE synchronisation follows
   p3_timings tm{};
 };
 
