@@ -281,6 +281,11 @@ uint32_t p3_rs_log2_for(uint64_t max_solid_sb);
  * segment, records the fixed-stride layout of one sweep addresses, 1 if the LDS-slice form is used}.  The layout must stay
  * below 2^32 (32-bit record offsets) whenever out[5] is 1. */
 int p3_probe_plan(uint64_t n_keys, uint32_t H, uint64_t m_bits, uint32_t boost_level, uint64_t out[6]);
+/* Host arithmetic, no device needed (tests): records per (bucket, workgroup) segment that the first-level partition of
+ * n_words stream words holding `windows` window instances is laid out for at a boost level (windows = 0: the stream-word
+ * bound).  Position chunks lay out ONE region size for all chunks from the first, largest chunk: no later chunk may ask
+ * for more. */
+uint32_t p3_segment_capacity(uint64_t n_words, uint64_t windows, uint32_t boost_level);
 int p3_mr_solid_build(p3_ctx* ctx, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes,
                       uint64_t* owned_bytes, uint64_t* total_bytes);
 /* Return-path gate (gate_mode 2, the default when the input fits): after p3_mr_count_owned the owner holds,

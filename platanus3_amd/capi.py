@@ -97,6 +97,8 @@ def load(build=False):
     L.p3_build_graph_from.argtypes = [vp, vp, C.c_uint64]
     L.p3_count_digest.argtypes = [vp, vp]
     L.p3_probe_plan.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, vp]
+    L.p3_segment_capacity.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+    L.p3_segment_capacity.restype = C.c_uint32
     L.p3_get_graph_stats.argtypes = [vp, C.POINTER(GraphStats)]
     L.p3_export_junctions.argtypes = [vp, vp, vp, vp, vp, u64, C.POINTER(u64)]
     L.p3_export_straights.argtypes = [vp, vp, vp, u64, u64, C.POINTER(u64)]

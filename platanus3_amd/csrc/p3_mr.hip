@@ -150,6 +150,14 @@ int p3_probe_plan(uint64_t n_keys, uint32_t H, uint64_t m_bits, uint32_t boost_l
   return P3_OK;
 }
 
+uint32_t p3_segment_capacity(uint64_t n_words, uint64_t windows, uint32_t boost_level) {
+  // (the arithmetic of part_local: windows known -> the busiest workgroup's share of them, else the stream-word bound)
+  u64 per = (n_words + P3_NWG - 1) / P3_NWG;
+  per = (per + P3_PART_THREADS - 1) / P3_PART_THREADS * P3_PART_THREADS;
+  const double mean = windows ? (double)windows * 1.02 / ((double)P3_NB * active_wgs(n_words)) : (double)(per * 32) / P3_NB;
+  return segcap_at(mean, boost_level);
+}
+
 int p3_mr_solid_build(p3_ctx* c, uint32_t rs_log2, void** d_solid, uint64_t* owned_offset_bytes, uint64_t* owned_bytes,
                       uint64_t* total_bytes) {
   if (!c || !d_solid || !owned_offset_bytes || !owned_bytes || !total_bytes) return P3_EBADARG;

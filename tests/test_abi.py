@@ -103,3 +103,33 @@ def test_probe_partition_layout_stays_within_its_32_bit_offsets():
     lvl0 = (int(out[1]), int(out[2]))
     assert L.p3_probe_plan(264_787_650, 19, 3_342_789_109, 1, out) == 0 and int(out[4]) < (1 << 32)
     assert (int(out[1]), int(out[2])) != lvl0 or int(out[5]) == 0
+
+
+def test_a_later_position_chunk_never_needs_more_room_than_the_first():
+    """p3_segment_capacity (host arithmetic of the partition step, no GPU).  Position chunks cut the stream into C equal
+    word ranges -- the last one shorter -- and lay out ONE region size for all of them from the first.  The estimate used to
+    divide by the number of workgroups that get ANY word: 8,218 words in 8 chunks = seven of 1,028 words (two workgroups:
+    1,024 + 4) and one of 1,022 (one workgroup) -- the last chunk asked for twice the first chunk's segments and the
+    partition step regrew what was a window of the chunks' common buffer (memory fault on the device).  With the busiest
+    workgroup's share as the divisor the first chunk is the largest, whatever the sizes."""
+    import numpy as np
+    from platanus3_amd import capi
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    cases = [(8218, 204540, 8)] + [(int(rng.integers(100, 5_000_000)), 0, int(rng.choice([2, 4, 8, 16]))) for _ in range(300)]
+    for n_words, windows, C in cases:
+        if not windows:
+            windows = int(n_words * 32 * rng.uniform(0.3, 1.0))
+        wc = (n_words + C - 1) // C
+        w0 = [min(i * wc, n_words) for i in range(C + 1)]
+        for level in (0, 1, 2):
+            caps = []
+            for ci in range(C):
+                nw = w0[ci + 1] - w0[ci]
+                if nw == 0:
+                    continue
+                hw = int(windows * nw / n_words) + 1
+                caps.append(L.p3_segment_capacity(nw, hw, level))
+            assert caps and max(caps) == caps[0], (n_words, windows, C, level, caps)
+    # the stream-word bound (no window count from the host) is monotonic in the words as well
+    assert L.p3_segment_capacity(1028, 0, 0) >= L.p3_segment_capacity(1022, 0, 0)
